@@ -1,0 +1,187 @@
+/*
+ * realvsr_hip.h -- C ABI of librealvsr_hip.so: the MI355X (gfx950) implementation of RealVSR's
+ * EDVR alignment / fusion / reconstruction / pyramid-loss hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers (float32, NCHW, contiguous unless a batch stride is stated) + sizes;
+ *     no torch / ATen types.  The caller owns every buffer; the library keeps no global state
+ *     and allocates nothing (temporaries come in through `workspace`).
+ *   - `stream` is a hipStream_t (NULL = default stream).  Launches are asynchronous; the call is
+ *     re-entrant across devices/streams (the caller sets the current device, as
+ *     at::DeviceGuard does in the reference: deform_conv_cuda.cpp:499,581).
+ *   - return value: 0 = ok, RVSR_ERR_* otherwise; rvsr_last_error() gives the message for the
+ *     calling thread.  (The reference only printf()s launch errors, kernel.cu:794-798; shape
+ *     errors there are c10::Error -> RuntimeError, deform_conv_cuda.cpp:497-516.)
+ *
+ * Section 1 is the drop-in for the reference's pybind module `deform_conv_cuda`
+ * (codes/models/archs/dcn/src/deform_conv_cuda.cpp:687-701).  Sections 2-4 replace the ATen /
+ * cuDNN calls the reference's Python makes on the same path (nn.Conv2d, F.interpolate, pooling,
+ * pixel_shuffle, the TSA element-wise chain, utils/util.py pyramids, Charbonnier loss).
+ */
+#ifndef REALVSR_HIP_H
+#define REALVSR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVSR_OK 0
+#define RVSR_ERR_UNSUPPORTED 1 /* valid request, not implemented on the HIP path (e.g. 5x5 DCN) */
+#define RVSR_ERR_BAD_ARG 2     /* null pointer / inconsistent shapes                              */
+#define RVSR_ERR_LAUNCH 3      /* HIP launch error                                                */
+#define RVSR_ERR_WORKSPACE 4   /* workspace missing or too small                                  */
+
+const char* rvsr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Modulated deformable convolution (DCNv2)
+ * --------------------------------------------------------------------------------------------- */
+
+/* Replaces modulated_deform_conv_cuda_forward (deform_conv_cuda.cpp:490-569) +
+ * modulated_deformable_im2col_cuda (deform_conv_cuda_kernel.cu:571-633, 769-799).
+ *   input (B,C,H,W)  weight (Co,C,kh,kw)  bias (Co) or NULL  offset (B,2*dg*kh*kw,Ho,Wo)
+ *   mask (B,dg*kh*kw,Ho,Wo)  output (B,Co,Ho,Wo) -- fully overwritten.
+ * The reference's `ones` / `columns` temporaries do not exist here (the column tile lives in LDS).
+ * HIP path: kh = kw = 3, group = 1, isotropic stride/pad/dilation, C/dg dividing or a multiple of 8. */
+int rvsr_modulated_deform_conv_forward(const float* input, const float* weight, const float* bias,
+                                       const float* offset, const float* mask, float* output,
+                                       int batch, int channels, int height, int width, int channels_out,
+                                       int kernel_h, int kernel_w, int stride_h, int stride_w,
+                                       int pad_h, int pad_w, int dilation_h, int dilation_w,
+                                       int group, int deformable_group, int with_bias, void* stream);
+
+/* Replaces modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:571-685) + the col2im /
+ * col2im_coord / im2col kernels (deform_conv_cuda_kernel.cu:571-767).
+ *   grad_input (B,C,H,W): must be zero on entry (scatter-add, as the reference: deform_conv.py:127)
+ *   grad_offset, grad_mask: overwritten.   grad_weight, grad_bias: accumulated into (+=), the
+ *   caller zeroes them (deform_conv.py:130-131, cpp:659-671).
+ *   grad_input/grad_offset/grad_mask may be NULL together (skip), grad_weight may be NULL (skip).
+ *   workspace: rvsr_modulated_deform_conv_backward_workspace_bytes() bytes, needed iff grad_weight. */
+size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch, int channels, int height, int width,
+                                                           int channels_out, int stride, int pad, int dil);
+int rvsr_modulated_deform_conv_backward(const float* input, const float* weight, const float* bias,
+                                        const float* offset, const float* mask, float* grad_input,
+                                        float* grad_weight, float* grad_bias, float* grad_offset,
+                                        float* grad_mask, const float* grad_output,
+                                        int batch, int channels, int height, int width, int channels_out,
+                                        int kernel_h, int kernel_w, int stride_h, int stride_w,
+                                        int pad_h, int pad_w, int dilation_h, int dilation_w,
+                                        int group, int deformable_group, int with_bias,
+                                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused core of ModulatedDeformConvPack.forward (deform_conv.py:274-292): `om` is the raw
+ * (B,3*dg*9,Ho,Wo) output of conv_offset_mask; torch.chunk/torch.cat become addressing (channels
+ * [0,2*dg*9) are the offsets, the rest mask logits) and torch.sigmoid runs in-kernel.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) applied to the output (EDVR_arch.py:107,130). */
+int rvsr_dcn_pack_forward(const float* input, const float* weight, const float* bias, const float* om,
+                          float* output, int batch, int channels, int height, int width, int channels_out,
+                          int stride, int pad, int dilation, int deformable_group, int act, float slope,
+                          void* stream);
+/* act_out (NULL or the saved activation output) fuses the activation derivative into the
+ * grad_output load.  grad_om (B,3*dg*9,Ho,Wo) is overwritten (d/d logit for the mask part);
+ * grad_input zero on entry; grad_weight/grad_bias accumulated. */
+int rvsr_dcn_pack_backward(const float* input, const float* weight, const float* om, const float* grad_output,
+                           const float* act_out, float act_slope, float* grad_input, float* grad_weight,
+                           float* grad_bias, float* grad_om, int batch, int channels, int height, int width,
+                           int channels_out, int stride, int pad, int dilation, int deformable_group,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Convolution blocks (nn.Conv2d 3x3 / 1x1, padding = ksize/2) with fused neighbours
+ *    (EDVR_arch.py:96-132, 166-208, 256-319; arch_util.py:121-139)
+ * --------------------------------------------------------------------------------------------- */
+
+/* out = act(conv(cat(x1, x2)) + bias) [+ residual]
+ *   x1 (B,C1,..), x2 (B,C2,..) or NULL/0: torch.cat([x1,x2],1) without materialising it.
+ *   in_mode 0: x1 is (B,C1,Hs,Ws).
+ *   in_mode 1: x1 is read through a zero-inserted x2 view of virtual size (Hout,Wout)
+ *              (data gradient of a stride-2 conv).
+ *   in_mode 2: x1 is stored (B,C1/4,Hs,Ws) and read pixel-unshuffled as (B,C1,Hs/2,Ws/2)
+ *              (gradient arriving through nn.PixelShuffle(2), EDVR_arch.py:311-312).
+ *   xact (NULL or a tensor stored like x1): value *= (xact > 0 ? 1 : xact_slope), i.e. the
+ *              ReLU / LeakyReLU derivative taken from the saved activation output.
+ *   weight: w_mode 0 -> (Co, C1+C2, k, k) used as is;
+ *           w_mode 1 -> (C1+C2, Co, k, k) used transposed + spatially flipped (data gradient).
+ *   out1 (B,Co1,Hout,Wout) [+ out2 (B,Co2,Hout,Wout): rows split, for the gradient of a cat].
+ *   residual (NULL or shaped like out1, out2 must be NULL): added after the activation.
+ *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ *   pixel_shuffle 1: out1 is (B,Co/4,2*Hout,2*Wout), written through PixelShuffle(2).
+ *   stride 2 only with ksize 3 and in_mode 0. */
+int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const float* xact, float xact_slope,
+                        int in_mode, int Hs, int Ws, const float* weight, const float* bias,
+                        const float* residual, float* out1, int Co1, float* out2, int Co2, int B, int ksize,
+                        int stride, int w_mode, int act, float slope, int pixel_shuffle, int Hout, int Wout,
+                        void* stream);
+
+/* grad_weight (Co,C1+C2,k,k) and grad_bias (Co) (NULL = skip) of the conv above.
+ *   gout: gradient w.r.t. the conv output.  g_mode 0: stored (B,Co,Gs_h,Gs_w) = (.., Hout, Wout);
+ *         g_mode 2: stored (B,Co/4,Gs_h,Gs_w) pixel-shuffled (2*Hout, 2*Wout).
+ *   gact/gact_slope: fused activation derivative (stored like gout), or NULL.
+ *   accumulate 0: overwrite, 1: += .  Deterministic (fixed-order reduction of partials). */
+size_t rvsr_conv2d_wgrad_workspace_bytes(int C1, int C2, int Co, int B, int ksize, int stride, int Hout, int Wout);
+int rvsr_conv2d_backward_weight(const float* x1, int C1, const float* x2, int C2, int Hin, int Win,
+                                const float* gout, const float* gact, float gact_slope, int g_mode,
+                                int Gs_h, int Gs_w, float* grad_weight, float* grad_bias, int Co, int B,
+                                int ksize, int stride, int Hout, int Wout, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. Fusion / resampling element-wise chain
+ * --------------------------------------------------------------------------------------------- */
+
+/* scale * F.interpolate(x, scale_factor=factor, mode='bilinear', align_corners=False), factor 2|4
+ * (EDVR_arch.py:111-112,115,120-121,124,194,200,316).  in: `planes` images of HxW. */
+int rvsr_upsample_bilinear_forward(const float* in, float* out, size_t planes, int H, int W, int factor,
+                                   float scale, void* stream);
+int rvsr_upsample_bilinear_backward(const float* gout, float* gin, size_t planes, int H, int W, int factor,
+                                    float scale, void* stream);
+
+/* cat([MaxPool2d(3,2,1)(x), AvgPool2d(3,2,1)(x)], 1) (EDVR_arch.py:154-155,188-194):
+ * in (B,C,H,W) -> out (B,2C,Ho,Wo), argmax (B,C,Ho,Wo) uint8 saved for the backward. */
+int rvsr_maxavgpool_forward(const float* in, float* out, unsigned char* argmax, int B, int C, int H, int W,
+                            void* stream);
+int rvsr_maxavgpool_backward(const float* gout, const unsigned char* argmax, float* gin, int B, int C, int H,
+                             int W, void* stream);
+
+/* TSA temporal attention (EDVR_arch.py:171-181): prob[b,n] = sigmoid(sum_c emb[b,n,c]*emb_ref[b,c]);
+ * mod[b,n,c] = aligned[b,n,c] * prob[b,n].  emb/aligned/mod (B,N,C,H,W), emb_ref (B,C,H,W),
+ * prob (B,N,H,W). */
+int rvsr_tsa_temporal_forward(const float* emb, const float* emb_ref, const float* aligned, float* mod,
+                              float* prob, int B, int N, int C, int H, int W, void* stream);
+int rvsr_tsa_temporal_backward(const float* gmod, const float* emb, const float* emb_ref, const float* aligned,
+                               const float* prob, float* galigned, float* gemb, float* gemb_ref, int B, int N,
+                               int C, int H, int W, void* stream);
+
+/* out = fea * sigmoid(att) * 2 + att_add (EDVR_arch.py:204-207); grad w.r.t. att_add is g itself. */
+int rvsr_tsa_output_forward(const float* fea, const float* att, const float* att_add, float* out, size_t n,
+                            void* stream);
+int rvsr_tsa_output_backward(const float* g, const float* fea, const float* att, float* gfea, float* gatt,
+                             size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 4. Laplacian pyramid decomposition + Charbonnier loss (utils/util.py:491-554, loss.py:10-23)
+ * --------------------------------------------------------------------------------------------- */
+
+/* downsample(conv_gauss(x)): reflect-pad 2, 5x5 binomial /256, keep even rows/cols.
+ * in: `planes` images HxW -> out ceil(H/2) x ceil(W/2).  (utils/util.py:503-510) */
+int rvsr_pyr_down_forward(const float* in, float* out, size_t planes, int H, int W, void* stream);
+int rvsr_pyr_down_backward(const float* gout, float* gin, size_t planes, int H, int W, void* stream);
+/* out = cur - upsample(down): zero-insert at even positions, reflect-pad 2, 5x5 binomial * 4/256
+ * (utils/util.py:513-516, 548-551).  H, W even; down is (H/2, W/2).
+ * backward: grad_cur = gout (identity), grad_down computed here. */
+int rvsr_pyr_updiff_forward(const float* cur, const float* down, float* out, size_t planes, int H, int W,
+                            void* stream);
+int rvsr_pyr_updiff_backward(const float* gout, float* gdown, size_t planes, int H, int W, void* stream);
+
+/* out[0] = scale * sum(sqrt((x-y)^2 + eps))  (scale = 1/n for reduction='mean'). */
+size_t rvsr_charbonnier_workspace_bytes(void);
+int rvsr_charbonnier_forward(const float* x, const float* y, size_t n, float eps, double scale, float* out,
+                             void* workspace, void* stream);
+/* gx = gscalar[0] * scale * (x-y)/sqrt((x-y)^2+eps); gscalar is a device pointer (no host sync). */
+int rvsr_charbonnier_backward(const float* x, const float* y, const float* gscalar, float scale, float eps,
+                              float* gx, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REALVSR_HIP_H */

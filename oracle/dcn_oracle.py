@@ -1,0 +1,145 @@
+"""oracle/dcn_oracle.py -- TEST INFRASTRUCTURE ONLY (not product code).
+
+CPU restatement of the reference's modulated deformable convolution operator:
+
+* device kernels  -> oracle/dcn_oracle.c (im2col / col2im / col2im_coord)
+* host code       -> this file, following
+    codes/models/archs/dcn/src/deform_conv_cuda.cpp:490-569 (forward: per-sample im2col +
+      addmm with weight.flatten(1), bias added last) and
+    codes/models/archs/dcn/src/deform_conv_cuda.cpp:571-685 (backward: col_grad = W^T gOut,
+      col2im_coord, col2im, im2col recompute, gW += gOut col^T, gBias += gOut 1),
+* autograd glue   -> codes/models/archs/dcn/deform_conv.py:97-153 (ModulatedDeformConvFunction).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (realvsr_amd) never does: it raises when its HIP library is missing.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile oracle/liboracle_dcn.so with gcc (idempotent)."""
+    so = os.path.join(_HERE, 'liboracle_dcn.so')
+    src = os.path.join(_HERE, 'dcn_oracle.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-s'])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return '_f32'
+    if t.dtype == torch.float64:
+        return '_f64'
+    raise TypeError('oracle DCN supports float32/float64, got %s' % t.dtype)
+
+
+def _geom(x, weight, stride, padding, dilation):
+    kh, kw = weight.shape[2:4]
+    H, W = x.shape[2:4]
+    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    return kh, kw, H, W, Ho, Wo
+
+
+def _ints(*a):
+    return [ctypes.c_int(int(v)) for v in a]
+
+
+def im2col(x_b, off_b, msk_b, kh, kw, stride, padding, dilation, dg, Ho, Wo):
+    C, H, W = x_b.shape
+    col = torch.empty(C * kh * kw, Ho * Wo, dtype=x_b.dtype)
+    fn = getattr(_lib(), 'oracle_modulated_im2col' + _suffix(x_b))
+    fn(_ptr(x_b), _ptr(off_b), _ptr(msk_b),
+       *_ints(C, H, W, Ho, Wo, kh, kw, padding, padding, stride, stride, dilation, dilation, dg),
+       _ptr(col))
+    return col
+
+
+class ModulatedDeformConvOracle(torch.autograd.Function):
+    """Same call signature as the reference's ``modulated_deform_conv``
+    (deform_conv.py:99-100): (input, offset, mask, weight, bias, stride, padding, dilation,
+    groups, deformable_groups)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1,
+                groups=1, deformable_groups=1):
+        assert not input.is_cuda, 'oracle runs on CPU tensors only'
+        x = input.contiguous()
+        offset = offset.contiguous()
+        mask = mask.contiguous()
+        weight = weight.contiguous()
+        B, C = x.shape[:2]
+        Co = weight.shape[0]
+        kh, kw, H, W, Ho, Wo = _geom(x, weight, stride, padding, dilation)
+        assert C == weight.shape[1] * groups
+        ctx.cfg = (stride, padding, dilation, groups, deformable_groups, bias is not None)
+        ctx.save_for_backward(x, offset, mask, weight)
+        out = torch.zeros(B, Co, Ho, Wo, dtype=x.dtype)
+        cg, og = C // groups, Co // groups
+        for b in range(B):  # cpp:539-561 -- one im2col + `groups` GEMMs per sample
+            col = im2col(x[b], offset[b], mask[b], kh, kw, stride, padding, dilation,
+                         deformable_groups, Ho, Wo)
+            for g in range(groups):
+                wg = weight[g * og:(g + 1) * og].flatten(1)
+                out[b, g * og:(g + 1) * og] = (wg @ col[g * cg * kh * kw:(g + 1) * cg * kh * kw]
+                                                ).view(og, Ho, Wo)
+        if bias is not None:  # cpp:566-568
+            out += bias.view(1, -1, 1, 1)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, offset, mask, weight = ctx.saved_tensors
+        stride, padding, dilation, groups, dg, with_bias = ctx.cfg
+        gout = grad_output.contiguous()
+        B, C = x.shape[:2]
+        Co = weight.shape[0]
+        kh, kw, H, W, Ho, Wo = _geom(x, weight, stride, padding, dilation)
+        K = kh * kw
+        sfx = _suffix(x)
+        lib = _lib()
+        gx = torch.zeros_like(x)
+        goff = torch.zeros_like(offset)
+        gmask = torch.zeros_like(mask)
+        gw = torch.zeros_like(weight)
+        gb = torch.zeros(Co, dtype=x.dtype)
+        cg, og = C // groups, Co // groups
+        geo = _ints(C, H, W, Ho, Wo, kh, kw, padding, padding, stride, stride, dilation,
+                    dilation, dg)
+        for b in range(B):
+            col_grad = torch.empty(C * K, Ho * Wo, dtype=x.dtype)
+            for g in range(groups):  # cpp:623-626
+                wg = weight[g * og:(g + 1) * og].flatten(1)
+                col_grad[g * cg * K:(g + 1) * cg * K] = wg.t() @ gout[b, g * og:(g + 1) * og].flatten(1)
+            getattr(lib, 'oracle_modulated_col2im_coord' + sfx)(  # cpp:634-638
+                _ptr(col_grad), _ptr(x[b]), _ptr(offset[b]), _ptr(mask[b]), *geo,
+                _ptr(goff[b]), _ptr(gmask[b]))
+            getattr(lib, 'oracle_modulated_col2im' + sfx)(  # cpp:640-643
+                _ptr(col_grad), _ptr(offset[b]), _ptr(mask[b]), *geo, _ptr(gx[b]))
+            col = im2col(x[b], offset[b], mask[b], kh, kw, stride, padding, dilation, dg, Ho, Wo)
+            for g in range(groups):  # cpp:659-671
+                go = gout[b, g * og:(g + 1) * og].flatten(1)
+                gw[g * og:(g + 1) * og] += (go @ col[g * cg * K:(g + 1) * cg * K].t()).view(og, cg, kh, kw)
+                gb[g * og:(g + 1) * og] += go.sum(1)
+        return (gx, goff, gmask, gw, gb if with_bias else None, None, None, None, None, None)
+
+
+modulated_deform_conv = ModulatedDeformConvOracle.apply

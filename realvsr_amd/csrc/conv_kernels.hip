@@ -1,0 +1,473 @@
+// conv_kernels.hip -- 3x3 / 1x1 convolution blocks of the EDVR hot path as implicit GEMMs on the
+// gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, see rvsr_common.h).
+//
+// Replaces, on the hot path, the reference's nn.Conv2d calls + the elementwise ops around them
+// (codes/models/archs/EDVR_arch.py:96-132,166-208,256-319; arch_util.py:121-139):
+//   * bias + ReLU / LeakyReLU(0.1) + residual add fused in the epilogue,
+//   * torch.cat([a, b], 1) never materialised (two input pointers),
+//   * nn.PixelShuffle(2) fused into the store (forward) / the load (backward),
+//   * activation derivative fused into the gradient load (TView.act),
+//   * data gradient = the same kernel with transposed+flipped weight addressing (w_mode 1),
+//     stride-2 data gradient through a zero-inserted view (TView mode 1),
+//   * weight gradient: persistent workgroups accumulate gW tiles in registers over many pixel
+//     tiles, write deterministic partials, a second kernel reduces them (no atomics).
+//
+// Tiling (forward): one workgroup = 4 waves = 8 x 32 output pixels x (MT * 32) output channels;
+// wave w owns rows 2w, 2w+1 (two 32-pixel N tiles) x MT M tiles.  K is walked in chunks of CC
+// input channels: the input tile (+halo) and the weight slice [tap][c][o] live in LDS; the B
+// operand is read straight out of the input tile at the tap's shifted address, so no im2col
+// buffer exists anywhere.
+#include "rvsr_common.h"
+
+struct ConvFwdParams {
+    TCat in;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* out1;
+    float* out2;
+    int Co1;
+    int B, Co, Hout, Wout;
+    int w_mode;
+    int act;
+    float slope;
+    int ps;
+    int ntx;
+};
+
+
+// MODE 0: plain store, 1: + residual, 2: channel split into out1/out2, 3: pixel-shuffle(2) store.
+// Branch-free per element except the final predicated store (the fully unrolled 16*MT*2 stores
+// otherwise explode into thousands of basic blocks and spill the accumulators).
+template <int MT, int MODE>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][2], const ConvFwdParams& p, int b, int o0, int row0,
+                                              int col, int hi) {
+    const bool has_bias = p.bias != nullptr;
+    const float* bp = has_bias ? p.bias : p.w;  // p.w: any valid address, value discarded
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+    const bool col_ok = col < p.Wout;
+    const size_t HW = (size_t)p.Hout * p.Wout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = row0 + n;
+        if (row >= p.Hout) continue;  // wave-uniform
+        const size_t pix = (size_t)row * p.Wout + col;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + m * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && o < p.Co;
+                const int oc = ok ? o : 0;
+                float v = acc[m][n][r];
+                const float bb = bp[oc];
+                v += has_bias ? bb : 0.f;
+                v = v > 0.f ? v : v * neg;
+                if (MODE == 3) {
+                    const size_t idx = (((size_t)b * (p.Co >> 2) + (oc >> 2)) * (2 * p.Hout) + 2 * row + ((oc >> 1) & 1)) *
+                                           (2 * p.Wout) + 2 * col + (oc & 1);
+                    if (ok) p.out1[idx] = v;
+                } else if (MODE == 2) {
+                    const bool first = oc < p.Co1;
+                    float* dst = first ? p.out1 : p.out2;
+                    const size_t idx = ((size_t)b * (first ? p.Co1 : p.Co - p.Co1) + (first ? oc : oc - p.Co1)) * HW + pix;
+                    if (ok) dst[idx] = v;
+                } else {
+                    const size_t idx = ((size_t)b * p.Co + oc) * HW + pix;
+                    if (ok) {
+                        if (MODE == 1) v += p.res[idx];
+                        p.out1[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int MT, int CC>
+__global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd_kernel(const ConvFwdParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2, TH = 8, TW = 32;
+    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    constexpr int MP = MT * 32, MPP = MP + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                  // [CC][IH][IW]
+    float* ws = smem + CC * IH * IW;   // [T][CC][MPP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int tx = blockIdx.x % p.ntx, ty = blockIdx.x / p.ntx;
+    const int x0 = tx * TW, y0 = ty * TH, mb = blockIdx.y, b = blockIdx.z;
+    const int Ctot = p.in.a.C + p.in.b.C;
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        acc[m][0] = zero16();
+        acc[m][1] = zero16();
+    }
+
+    for (int c0 = 0; c0 < Ctot; c0 += CC) {
+#pragma unroll 2
+        for (int e = tid; e < CC * IH * IW; e += RVSR_WG) {
+            const int cc = e / (IH * IW);
+            const int rem = e - cc * (IH * IW);
+            const int r = rem / IW, s = rem - r * IW;
+            const int c = c0 + cc;
+            float v = 0.f;
+            if (c < Ctot) v = tcat_get(p.in, b, c, y0 * STRIDE - PAD + r, x0 * STRIDE - PAD + s);
+            xs[e] = v;
+        }
+        if (p.w_mode == 0) {  // A[o][(tap, c)] = w[o][c][tap]
+#pragma unroll 4
+            for (int e = tid; e < MP * CC * T; e += RVSR_WG) {
+                const int m = e / (CC * T);
+                const int rem = e - m * (CC * T);
+                const int cc = rem / T, tap = rem - cc * T;
+                const int o = mb * MP + m, c = c0 + cc;
+                float v = 0.f;
+                if (o < p.Co && c < Ctot) v = p.w[((size_t)o * Ctot + c) * T + tap];
+                ws[(tap * CC + cc) * MPP + m] = v;
+            }
+        } else {  // data gradient: A[i][(tap, k)] = w[k][i][T-1-tap], w stored [Ctot][Co][T]
+#pragma unroll 4
+            for (int e = tid; e < CC * MP * T; e += RVSR_WG) {
+                const int cc = e / (MP * T);
+                const int rem = e - cc * (MP * T);
+                const int m = rem / T, tap = rem - m * T;
+                const int i = mb * MP + m, k = c0 + cc;
+                float v = 0.f;
+                if (i < p.Co && k < Ctot) v = p.w[((size_t)k * p.Co + i) * T + (T - 1 - tap)];
+                ws[(tap * CC + cc) * MPP + m] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            const int dy = tap / KS, dx = tap % KS;
+#pragma unroll 4
+            for (int cp = 0; cp < CC / 2; ++cp) {
+                const int cc = 2 * cp + hi;
+                float a[MT], bv[2];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = ws[(tap * CC + cc) * MPP + m * 32 + lo];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    bv[n] = xs[cc * (IH * IW) + ((wave * 2 + n) * STRIDE + dy) * IW + lo * STRIDE + dx];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m][0] = mfma32(a[m], bv[0], acc[m][0]);
+                    acc[m][1] = mfma32(a[m], bv[1], acc[m][1]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: bias + activation (+ residual | pixel-shuffle | channel split), 128-B row segments
+    if (p.ps)
+        conv_epilogue<MT, 3>(acc, p, b, mb * (MT * 32), y0 + wave * 2, x0 + lo, hi);
+    else if (p.out2 != nullptr)
+        conv_epilogue<MT, 2>(acc, p, b, mb * (MT * 32), y0 + wave * 2, x0 + lo, hi);
+    else if (p.res != nullptr)
+        conv_epilogue<MT, 1>(acc, p, b, mb * (MT * 32), y0 + wave * 2, x0 + lo, hi);
+    else
+        conv_epilogue<MT, 0>(acc, p, b, mb * (MT * 32), y0 + wave * 2, x0 + lo, hi);
+}
+
+// ------------------------------------------------------------------------------------------
+struct ConvWgradParams {
+    TCat x;      // the conv's (virtual) input
+    TView g;     // gradient w.r.t. the conv output: virtual (Co, Hout, Wout); g.act fuses act'
+    float* part;   // [P][Co][Ctot][T]
+    float* bpart;  // [P][Co] or nullptr
+    int B, Co, Hout, Wout, ntx, nty, P;
+};
+
+template <int KS, int STRIDE, int CCW>
+__global__ __launch_bounds__(RVSR_WG) void conv_wgrad_kernel(const ConvWgradParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2, TH = 4, TW = 32, NPX = TH * TW;
+    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    constexpr int CS = (IH * IW) | 1;  // odd channel stride: lanes walk channels conflict-free
+    constexpr int NTOT = T * CCW, NT = (NTOT + 31) / 32, TPW = (2 * NT + 3) / 4;
+    constexpr int GP = 65;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* gT = smem;             // [NPX][GP]   gradient tile, pixel-major
+    float* xs = smem + NPX * GP;  // [CCW][CS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int mb = blockIdx.y, c0 = blockIdx.z * CCW;
+    const int Ctot = p.x.a.C + p.x.b.C;
+    const int m = wave & 1;
+    const bool m_live = (mb * 64 + m * 32) < p.Co;
+
+    int boff[TPW];
+    bool bval[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int nt = (wave >> 1) + 2 * i;
+        const int n = nt * 32 + lo;
+        bval[i] = (nt < NT) && (n < NTOT);
+        const int tap = n / CCW, cc = n - tap * CCW;
+        boff[i] = bval[i] ? cc * CS + (tap / KS) * IW + (tap % KS) : 0;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = zero16();
+    float bsum = 0.f;
+
+    const int ntiles = p.B * p.nty * p.ntx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.P) {
+        const int b = tile / (p.nty * p.ntx);
+        const int trem = tile - b * (p.nty * p.ntx);
+        const int ty = trem / p.ntx, tx = trem - ty * p.ntx;
+        const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll 2
+        for (int e = tid; e < 64 * NPX; e += RVSR_WG) {
+            const int ol = e / NPX, px = e - ol * NPX;
+            const int o = mb * 64 + ol;
+            float v = 0.f;
+            if (o < p.Co) v = tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31));
+            gT[px * GP + ol] = v;
+        }
+#pragma unroll 2
+        for (int e = tid; e < CCW * IH * IW; e += RVSR_WG) {
+            const int cc = e / (IH * IW);
+            const int rem = e - cc * (IH * IW);
+            const int r = rem / IW, s = rem - r * IW;
+            const int c = c0 + cc;
+            float v = 0.f;
+            if (c < Ctot) v = tcat_get(p.x, b, c, y0 * STRIDE - PAD + r, x0 * STRIDE - PAD + s);
+            xs[cc * CS + r * IW + s] = v;
+        }
+        __syncthreads();
+        if (p.bpart != nullptr && blockIdx.z == 0 && tid < 64) {
+            float s = 0.f;
+            for (int px = 0; px < NPX; ++px) s += gT[px * GP + tid];
+            bsum += s;
+        }
+        if (m_live) {
+#pragma unroll 2
+            for (int ks = 0; ks < NPX / 2; ++ks) {
+                const int row = ks >> 4, colp = 2 * (ks & 15) + hi;
+                const float a = gT[(row * 32 + colp) * GP + m * 32 + lo];
+                const int poff = row * STRIDE * IW + colp * STRIDE;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    if ((wave >> 1) + 2 * i < NT) {
+                        const float bv = bval[i] ? xs[boff[i] + poff] : 0.f;
+                        acc[i] = mfma32(a, bv, acc[i]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (m_live) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int nt = (wave >> 1) + 2 * i;
+            const int n = nt * 32 + lo;
+            if (nt >= NT || n >= NTOT) continue;
+            const int tap = n / CCW, c = c0 + (n - tap * CCW);
+            if (c >= Ctot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mb * 64 + m * 32 + drow(r, hi);
+                if (o < p.Co) p.part[(((size_t)blockIdx.x * p.Co + o) * Ctot + c) * T + tap] = acc[i][r];
+            }
+        }
+    }
+    if (p.bpart != nullptr && blockIdx.z == 0 && tid < 64) {
+        const int o = mb * 64 + tid;
+        if (o < p.Co) p.bpart[(size_t)blockIdx.x * p.Co + o] = bsum;
+    }
+}
+
+// dst[i] (+)= sum_p part[p][i]   (fixed summation order -> run-to-run deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst,
+                                       int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < P; ++q) s += part[(size_t)q * n + i];
+        dst[i] = accumulate ? dst[i] + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+
+
+template <int KS, int STRIDE, int MT, int CC>
+static int launch_fwd(const ConvFwdParams& p, hipStream_t st) {
+    constexpr int T = KS * KS, IH = 7 * STRIDE + KS, IW = 31 * STRIDE + KS;
+    const size_t lds = sizeof(float) * (CC * IH * IW + T * CC * (MT * 32 + 1));
+    auto k = conv_fwd_kernel<KS, STRIDE, MT, CC>;
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd: cannot reserve %zu B of LDS", lds);
+    const int nty = (p.Hout + 7) / 8;
+    dim3 grid(p.ntx * nty, (p.Co + MT * 32 - 1) / (MT * 32), p.B);
+    hipLaunchKernelGGL(k, grid, dim3(RVSR_WG), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_fwd launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+static int make_view(TView& v, const float* p, const float* act, float slope, int C, int Hs, int Ws, int mode,
+                     int Hv, int Wv) {
+    v.p = p;
+    v.act = act;
+    v.slope = slope;
+    v.C = C;
+    v.Hs = Hs;
+    v.Ws = Ws;
+    v.mode = mode;
+    if (mode == 0) {
+        v.Hv = Hs;
+        v.Wv = Ws;
+    } else if (mode == 1) {
+        v.Hv = Hv;
+        v.Wv = Wv;
+    } else if (mode == 2) {
+        if ((Hs | Ws) & 1 || C % 4) return 1;
+        v.Hv = Hs / 2;
+        v.Wv = Ws / 2;
+    } else {
+        return 1;
+    }
+    return 0;
+}
+
+// Fused conv block.  See include/realvsr_hip.h for the contract.
+extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const float* xact,
+                                   float xact_slope, int in_mode, int Hs, int Ws, const float* weight,
+                                   const float* bias, const float* residual, float* out1, int Co1, float* out2,
+                                   int Co2, int B, int ksize, int stride, int w_mode, int act, float slope,
+                                   int pixel_shuffle, int Hout, int Wout, void* stream) {
+    if (!x1 || !weight || !out1 || B <= 0 || C1 <= 0 || Co1 <= 0) FAIL(RVSR_ERR_BAD_ARG, "conv2d: null/empty argument");
+    if ((x2 == nullptr) != (C2 == 0) || (out2 == nullptr) != (Co2 == 0))
+        FAIL(RVSR_ERR_BAD_ARG, "conv2d: second input/output pointer and channel count disagree");
+    if (ksize != 1 && ksize != 3) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: kernel size %d (1 or 3 supported)", ksize);
+    if (stride != 1 && !(stride == 2 && ksize == 3)) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: stride %d", stride);
+    if (in_mode != 0 && (x2 != nullptr || stride != 1)) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: view mode with concat/stride");
+    if (xact && x2) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: act' fusion with concat input");
+    if ((residual || pixel_shuffle) && out2) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: residual/pixel-shuffle with split output");
+    if (residual && pixel_shuffle) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: residual with pixel-shuffle");
+    ConvFwdParams p;
+    if (make_view(p.in.a, x1, xact, xact_slope, C1, Hs, Ws, in_mode, Hout, Wout))
+        FAIL(RVSR_ERR_BAD_ARG, "conv2d: bad input view (mode %d, C %d, %dx%d)", in_mode, C1, Hs, Ws);
+    make_view(p.in.b, x2, nullptr, 0.f, C2, Hs, Ws, 0, 0, 0);
+    const int pad = ksize / 2;
+    const int He = (p.in.a.Hv + 2 * pad - ksize) / stride + 1, We = (p.in.a.Wv + 2 * pad - ksize) / stride + 1;
+    if (He != Hout || We != Wout) FAIL(RVSR_ERR_BAD_ARG, "conv2d: output size %dx%d, expected %dx%d", Hout, Wout, He, We);
+    p.w = weight;
+    p.bias = bias;
+    p.res = residual;
+    p.out1 = out1;
+    p.out2 = out2;
+    p.Co1 = Co1;
+    p.Co = Co1 + Co2;
+    if (pixel_shuffle && (p.Co % 4)) FAIL(RVSR_ERR_BAD_ARG, "conv2d: pixel-shuffle needs Co %% 4 == 0");
+    p.B = B;
+    p.Hout = Hout;
+    p.Wout = Wout;
+    p.w_mode = w_mode;
+    p.act = act;
+    p.slope = slope;
+    p.ps = pixel_shuffle;
+    p.ntx = (Wout + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    const int mt = p.Co <= 32 ? 1 : (p.Co <= 64 ? 2 : 4);
+#define DISPATCH(KS, S, CC12, CC4)                                \
+    do {                                                           \
+        if (mt == 1) return launch_fwd<KS, S, 1, CC12>(p, st);     \
+        if (mt == 2) return launch_fwd<KS, S, 2, CC12>(p, st);     \
+        return launch_fwd<KS, S, 4, CC4>(p, st);                   \
+    } while (0)
+    if (ksize == 3 && stride == 1) DISPATCH(3, 1, 16, 8);
+    if (ksize == 3 && stride == 2) DISPATCH(3, 2, 8, 4);
+    DISPATCH(1, 1, 32, 32);
+#undef DISPATCH
+}
+
+static int wgrad_P(int ntiles, int gy, int gz) {
+    int P = 512 / (gy * gz);
+    if (P < 1) P = 1;
+    if (P > ntiles) P = ntiles;
+    return P;
+}
+static void wgrad_geom(int ksize, int stride, int Co, int Ctot, int& ccw, int& gy, int& gz) {
+    ccw = (ksize == 3 && stride == 2) ? 32 : 64;
+    gy = (Co + 63) / 64;
+    gz = (Ctot + ccw - 1) / ccw;
+}
+
+extern "C" size_t rvsr_conv2d_wgrad_workspace_bytes(int C1, int C2, int Co, int B, int ksize, int stride, int Hout,
+                                                    int Wout) {
+    int ccw, gy, gz;
+    wgrad_geom(ksize, stride, Co, C1 + C2, ccw, gy, gz);
+    const int ntiles = B * ((Hout + 3) / 4) * ((Wout + 31) / 32);
+    const size_t P = wgrad_P(ntiles, gy, gz);
+    return sizeof(float) * P * ((size_t)Co * (C1 + C2) * ksize * ksize + Co);
+}
+
+template <int KS, int STRIDE, int CCW>
+static int launch_wgrad(const ConvWgradParams& p, int gy, int gz, hipStream_t st) {
+    constexpr int IH = 3 * STRIDE + KS, IW = 31 * STRIDE + KS, CS = (IH * IW) | 1;
+    const size_t lds = sizeof(float) * (128 * 65 + CCW * CS);
+    auto k = conv_wgrad_kernel<KS, STRIDE, CCW>;
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(k, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float* x2, int C2, int Hin, int Win,
+                                           const float* gout, const float* gact, float gact_slope, int g_mode,
+                                           int Gs_h, int Gs_w, float* grad_weight, float* grad_bias, int Co, int B,
+                                           int ksize, int stride, int Hout, int Wout, int accumulate, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (!x1 || !gout || !grad_weight || B <= 0) FAIL(RVSR_ERR_BAD_ARG, "conv2d_backward_weight: null/empty argument");
+    if ((x2 == nullptr) != (C2 == 0)) FAIL(RVSR_ERR_BAD_ARG, "conv2d_backward_weight: x2/C2 disagree");
+    if (ksize != 1 && ksize != 3) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d_backward_weight: kernel size %d", ksize);
+    if (stride != 1 && !(stride == 2 && ksize == 3)) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d_backward_weight: stride %d", stride);
+    if (g_mode != 0 && g_mode != 2) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d_backward_weight: gradient view mode %d", g_mode);
+    const size_t need = rvsr_conv2d_wgrad_workspace_bytes(C1, C2, Co, B, ksize, stride, Hout, Wout);
+    if (!workspace || workspace_bytes < need)
+        FAIL(RVSR_ERR_WORKSPACE, "conv2d_backward_weight: workspace %zu B < %zu B", workspace_bytes, need);
+    ConvWgradParams p;
+    make_view(p.x.a, x1, nullptr, 0.f, C1, Hin, Win, 0, 0, 0);
+    make_view(p.x.b, x2, nullptr, 0.f, C2, Hin, Win, 0, 0, 0);
+    if (make_view(p.g, gout, gact, gact_slope, Co, Gs_h, Gs_w, g_mode, 0, 0) || p.g.Hv != Hout || p.g.Wv != Wout)
+        FAIL(RVSR_ERR_BAD_ARG, "conv2d_backward_weight: gradient view %dx%d (mode %d) vs output %dx%d", Gs_h, Gs_w, g_mode,
+             Hout, Wout);
+    const int pad = ksize / 2;
+    if ((Hin + 2 * pad - ksize) / stride + 1 != Hout || (Win + 2 * pad - ksize) / stride + 1 != Wout)
+        FAIL(RVSR_ERR_BAD_ARG, "conv2d_backward_weight: input %dx%d does not give output %dx%d", Hin, Win, Hout, Wout);
+    int ccw, gy, gz;
+    const int Ctot = C1 + C2;
+    wgrad_geom(ksize, stride, Co, Ctot, ccw, gy, gz);
+    p.B = B;
+    p.Co = Co;
+    p.Hout = Hout;
+    p.Wout = Wout;
+    p.ntx = (Wout + 31) / 32;
+    p.nty = (Hout + 3) / 4;
+    p.P = wgrad_P(B * p.nty * p.ntx, gy, gz);
+    const size_t nw = (size_t)Co * Ctot * ksize * ksize;
+    p.part = (float*)workspace;
+    p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (ksize == 3 && stride == 1)
+        rc = launch_wgrad<3, 1, 64>(p, gy, gz, st);
+    else if (ksize == 3)
+        rc = launch_wgrad<3, 2, 32>(p, gy, gz, st);
+    else
+        rc = launch_wgrad<1, 1, 64>(p, gy, gz, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256)), dim3(256), 0,
+                       st, p.part, p.P, nw, grad_weight, accumulate);
+    if (grad_bias)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.bpart, p.P, (size_t)Co, grad_bias, accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad reduce launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}

@@ -1,0 +1,106 @@
+// rvsr_common.h -- shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// GEMM core: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bit-for-bit an fmaf chain), one
+// 32x32 output tile per wave-instruction, 64-wide wavefronts.  Operand/lane maps (gfx950):
+//   A[i][k]: lane l supplies A[i = l & 31][k = l >> 5]
+//   B[k][j]: lane l supplies B[k = l >> 5][j = l & 31]
+//   D[i][j]: lane l, register r holds D[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][j = l & 31]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RVSR_WG 256  // 4 waves of 64
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// row of the 32x32 D tile held in register r of lane-half hi (= lane >> 5)
+__device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Read-only view of an NCHW f32 activation with the input-side fusions the conv kernels need.
+//   mode 0: plain                      virtual (C, Hv, Wv) == stored (C, Hs, Ws)
+//   mode 1: zero-insert x2             virtual[c][2y][2x] = stored[c][y][x], 0 elsewhere
+//                                      (data-gradient of a stride-2 conv as a stride-1 conv)
+//   mode 2: pixel-unshuffle x2         virtual[c][y][x] = stored[c/4][2y + (c%4)/2][2x + c%2]
+//                                      (gradient arriving through nn.PixelShuffle(2))
+// `act` (optional) is a tensor stored exactly like `p`; the value is multiplied by
+// (act > 0 ? 1 : slope): the derivative of ReLU (slope 0) / LeakyReLU(slope) evaluated from the
+// saved activation OUTPUT, fused into the load so no separate elementwise pass is needed.
+struct TView {
+    const float* p;
+    const float* act;
+    float slope;
+    int C;       // virtual channels
+    int Hs, Ws;  // stored spatial size
+    int Hv, Wv;  // virtual spatial size
+    int mode;
+};
+
+__device__ __forceinline__ float tview_get(const TView& v, int b, int c, int y, int x) {
+    if (y < 0 || x < 0 || y >= v.Hv || x >= v.Wv) return 0.f;
+    size_t idx;
+    if (v.mode == 0) {
+        idx = (((size_t)b * v.C + c) * v.Hs + y) * v.Ws + x;
+    } else if (v.mode == 1) {
+        if ((y | x) & 1) return 0.f;
+        const int ys = y >> 1, xs = x >> 1;
+        if (ys >= v.Hs || xs >= v.Ws) return 0.f;
+        idx = (((size_t)b * v.C + c) * v.Hs + ys) * v.Ws + xs;
+    } else {
+        const int cs = c >> 2, sy = (c >> 1) & 1, sx = c & 1;
+        idx = (((size_t)b * (v.C >> 2) + cs) * v.Hs + (2 * y + sy)) * v.Ws + (2 * x + sx);
+    }
+    float val = v.p[idx];
+    if (v.act != nullptr) val *= (v.act[idx] > 0.f ? 1.f : v.slope);
+    return val;
+}
+
+// two views concatenated along channels (torch.cat([a, b], 1) without materialising it)
+struct TCat {
+    TView a, b;  // b.p == nullptr -> single input
+};
+__device__ __forceinline__ float tcat_get(const TCat& t, int bidx, int c, int y, int x) {
+    if (c < t.a.C) return tview_get(t.a, bidx, c, y, x);
+    c -= t.a.C;
+    if (t.b.p == nullptr || c >= t.b.C) return 0.f;
+    return tview_get(t.b, bidx, c, y, x);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side error plumbing (capi.hip)
+#define RVSR_OK 0
+#define RVSR_ERR_UNSUPPORTED 1
+#define RVSR_ERR_BAD_ARG 2
+#define RVSR_ERR_LAUNCH 3
+#define RVSR_ERR_WORKSPACE 4
+
+#include <stdio.h>
+// one error string per host thread, shared by all translation units (defined in misc_kernels.hip)
+extern thread_local char rvsr_g_err[256];
+#define FAIL(code, ...)                                        \
+    do {                                                       \
+        snprintf(rvsr_g_err, sizeof(rvsr_g_err), __VA_ARGS__); \
+        return code;                                           \
+    } while (0)
+
+template <typename K>
+static inline int set_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
+}

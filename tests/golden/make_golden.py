@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by IMPORTING the reference Python (build container only).
+
+Run from the repo root:   python tests/golden/make_golden.py
+Needs /root/reference (read-only).  The reference Python never travels to the GPU box; only
+the .npz data written here does.  Recipe = SURVEY.md Appendix B:
+  * stub the third-party modules the reference imports but the hot path never calls,
+  * replace the CUDA-only ``modulated_deform_conv`` with the CPU oracle (oracle/dcn_oracle.py),
+  * drive the reference's own PCD_Align / TSA_Fusion / EDVR / EDVR_NoUp / pyramid / loss code
+    with seeded tensors and record inputs, weights, outputs and gradients.
+Every array is float32 (or float64 where noted); files are kept small (tiny nf / sizes).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = '/root/reference/codes'
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, 'tests', 'golden'))
+from weights import fill_state_dict  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for name in ['kornia', 'cv2', 'ffmpeg', 'lmdb', 'IQA_pytorch', 'torchvision', 'torchvision.utils',
+                 'models.archs.dcn.deform_conv_cuda']:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    for cls in ['SSIM', 'MS_SSIM', 'DISTS', 'LPIPSvgg']:
+        setattr(sys.modules['IQA_pytorch'], cls, type(cls, (torch.nn.Module,), {}))
+    sys.modules['torchvision.utils'].make_grid = lambda *a, **k: None
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    import models.archs.dcn.deform_conv  # noqa: F401
+    from oracle.dcn_oracle import modulated_deform_conv as oracle_dcn
+    sys.modules['models.archs.dcn.deform_conv'].modulated_deform_conv = oracle_dcn
+    import models.archs.EDVR_arch as EDVR_arch
+    import models.loss as loss
+    import utils.util as util
+    return EDVR_arch, loss, util, sys.modules['models.archs.dcn.deform_conv']
+
+
+def np_sd(module):
+    return {'sd.' + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def np_grads(module):
+    return {'grad.' + k: p.grad.detach().numpy().copy() for k, p in module.named_parameters()}
+
+
+def randomize_offset_convs(module, std):
+    """conv_offset_mask is zero-initialised in the reference (deform_conv.py:270-272); give it
+    non-trivial weights so that offsets/masks are exercised."""
+    g = torch.Generator().manual_seed(99)
+    for name, p in module.named_parameters():
+        if 'conv_offset_mask' in name:
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-28s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def main():
+    torch.set_num_threads(4)
+    EDVR_arch, loss_mod, util, dc = import_reference()
+
+    # ---- 1. DCN pack: reference ModulatedDeformConvPack wiring + oracle operator ---------------
+    torch.manual_seed(1)
+    pack = dc.ModulatedDeformConvPack(16, 12, 3, stride=1, padding=1, dilation=1,
+                                      deformable_groups=4, extra_offset_mask=True)
+    randomize_offset_convs(pack, 0.3)  # |offset| up to several px -> border / out-of-range taps
+    x = torch.randn(2, 16, 7, 9, requires_grad=True)
+    feat = torch.randn(2, 16, 7, 9, requires_grad=True)
+    out = pack([x, feat])
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    save('dcn_pack', x=x.detach().numpy(), feat=feat.detach().numpy(), out=out.detach().numpy(),
+         gout=gout.numpy(), gx=x.grad.numpy(), gfeat=feat.grad.numpy(), **np_sd(pack), **np_grads(pack))
+
+    # ---- 2. raw operator with hand-made offsets (border, integer, far out of range) ------------
+    torch.manual_seed(2)
+    B, C, Co, dg, H, W = 2, 8, 6, 2, 6, 10
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    offset = (torch.randn(B, dg * 18, H, W) * 2.0)
+    offset[0, :, 0, :] = -1.5          # samples in (-1, 0) and below -1
+    offset[0, :, -1, :] = 1.25         # samples in (H-1, H)
+    offset[1, :, :, 0] = -40.0         # far out of range
+    offset[1, :, 2, :] = 1.0           # exact integer offsets
+    offset.requires_grad_(True)
+    mask = torch.rand(B, dg * 9, H, W, requires_grad=True)
+    weight = torch.randn(Co, C, 3, 3, requires_grad=True)
+    bias = torch.randn(Co, requires_grad=True)
+    out = dc.modulated_deform_conv(x, offset, mask, weight, bias, 1, 1, 1, 1, dg)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    save('dcn_op', x=x.detach().numpy(), offset=offset.detach().numpy(), mask=mask.detach().numpy(),
+         weight=weight.detach().numpy(), bias=bias.detach().numpy(), out=out.detach().numpy(),
+         gout=gout.numpy(), gx=x.grad.numpy(), goffset=offset.grad.numpy(), gmask=mask.grad.numpy(),
+         gweight=weight.grad.numpy(), gbias=bias.grad.numpy(), dg=np.int32(dg))
+
+    # ---- 3. PCD_Align ---------------------------------------------------------------------------
+    torch.manual_seed(3)
+    nf, groups = 16, 4
+    pcd = EDVR_arch.PCD_Align(nf=nf, groups=groups)
+    randomize_offset_convs(pcd, 0.05)
+    nbr = [torch.randn(1, nf, 16 >> l, 24 >> l, requires_grad=True) for l in range(3)]
+    ref = [torch.randn(1, nf, 16 >> l, 24 >> l, requires_grad=True) for l in range(3)]
+    out = pcd(nbr, ref)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    arrs = {}
+    for l in range(3):
+        arrs['nbr%d' % l] = nbr[l].detach().numpy()
+        arrs['ref%d' % l] = ref[l].detach().numpy()
+        arrs['gnbr%d' % l] = nbr[l].grad.numpy()
+        arrs['gref%d' % l] = ref[l].grad.numpy()
+    save('pcd_align', out=out.detach().numpy(), gout=gout.numpy(), nf=np.int32(nf), groups=np.int32(groups),
+         **arrs, **np_sd(pcd), **np_grads(pcd))
+
+    # ---- 4. TSA_Fusion --------------------------------------------------------------------------
+    torch.manual_seed(4)
+    tsa = EDVR_arch.TSA_Fusion(nf=16, nframes=3, center=1)
+    al = torch.randn(2, 3, 16, 12, 20, requires_grad=True)
+    out = tsa(al)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    save('tsa_fusion', aligned=al.detach().numpy(), out=out.detach().numpy(), gout=gout.numpy(),
+         galigned=al.grad.numpy(), **np_sd(tsa), **np_grads(tsa))
+
+    # ---- 5. EDVR (x4, TSA) and EDVR_NoUp (no TSA), tiny ----------------------------------------
+    for name, cls, kw in [('edvr_tsa', EDVR_arch.EDVR, dict(nf=16, nframes=3, groups=4, front_RBs=2, back_RBs=2, w_TSA=True)),
+                          ('edvr_noup', EDVR_arch.EDVR_NoUp, dict(nf=64, nframes=3, groups=8, front_RBs=1, back_RBs=1, w_TSA=False))]:
+        torch.manual_seed(5)
+        net = cls(nc=3, center=None, predeblur=False, HR_in=False, **kw)
+        if name == 'edvr_noup':  # nf must be 64 (EDVR_arch.py:352): weights re-created from a seed
+            fill_state_dict(net, 77)
+        else:
+            randomize_offset_convs(net, 0.02)
+        gen = torch.Generator().manual_seed(1234)
+        hw = (16, 24) if name == 'edvr_tsa' else (8, 12)
+        x = torch.rand(1, kw['nframes'], 3, *hw, generator=gen)
+        out = net(x)
+        gt = torch.rand(out.shape, generator=torch.Generator().manual_seed(1235))
+        crit = loss_mod.LapPyrLoss(num_levels=3, lf_mode='cb', hf_mode='cb', reduction='mean')
+        l = crit(out[:, 0:1], gt[:, 0:1]) + loss_mod.CharbonnierLoss()(out[:, 1:3], gt[:, 1:3])
+        l.backward()
+        gnorm = torch.sqrt(sum((p.grad ** 2).sum() for p in net.parameters()))
+        sd = np_sd(net)
+        grads = np_grads(net)
+        if name == 'edvr_noup':  # nf=64 model: keep the file small, store only a few gradients
+            sd = {}
+            grads = {k: v for k, v in grads.items() if k.split('grad.')[1] in (
+                'conv_first.weight', 'conv_first.bias', 'pcd_align.L1_dcnpack.weight',
+                'pcd_align.cas_dcnpack.conv_offset_mask.bias', 'conv_last.weight')}
+        save(name, x=x.numpy(), out=out.detach().numpy(), gt=gt.numpy(), loss=np.float64(l.item()),
+             gnorm=np.float64(gnorm.item()), **{k: np.asarray(v) for k, v in kw.items()}, **sd, **grads)
+
+    # ---- 6. pyramids on integer-valued inputs (exactly representable => bit-exact indexing) -----
+    arrs = {}
+    for tag, (C, H, W) in {'a': (1, 64, 64), 'b': (3, 36, 52), 'c': (1, 8, 12)}.items():
+        g = torch.Generator().manual_seed(60 + C + H)
+        img = torch.randint(0, 16, (2, C, H, W), generator=g).float()
+        k = util.gauss_kernel(channels=C)
+        arrs['img_' + tag] = img.numpy()
+        for i, lv in enumerate(util.laplacian_pyramid(img, k, 3)):
+            arrs['laplacian_%s_%d' % (tag, i)] = lv.numpy()
+        for i, lv in enumerate(util.lap_pyramid(img, k, 2)):
+            arrs['lap_%s_%d' % (tag, i)] = lv.numpy()
+        for i, lv in enumerate(util.gau_pyramid(img, k, 3)):
+            arrs['gau_%s_%d' % (tag, i)] = lv.numpy()
+    save('pyramid_int', **arrs)
+
+    # ---- 7. losses + gradients on float inputs --------------------------------------------------
+    torch.manual_seed(7)
+    arrs = {}
+    for tag, C in (('y', 1), ('rgb', 3)):
+        x = torch.rand(2, C, 24, 40, requires_grad=True)
+        y = torch.rand(2, C, 24, 40)
+        arrs['x_' + tag], arrs['y_' + tag] = x.detach().numpy(), y.numpy()
+        for lname, crit in [('lappyr_cb', loss_mod.LapPyrLoss(3, 'cb', 'cb', 'mean')),
+                            ('lappyr_cb_sum', loss_mod.LapPyrLoss(2, 'cb', 'cb', 'sum')),
+                            ('pyr_gau_cb', loss_mod.PyramidLoss(3, 'gau', 'cb', 'mean')),
+                            ('pyr_lap_l1', loss_mod.PyramidLoss(2, 'lap', 'l1', 'mean')),
+                            ('pyr_gau_l2', loss_mod.PyramidLoss(3, 'gau', 'l2', 'mean')),
+                            ('cb', loss_mod.CharbonnierLoss())]:
+            x.grad = None
+            l = crit(x, y)
+            l.backward()
+            arrs['%s_%s' % (lname, tag)] = np.float64(l.item())
+            arrs['g_%s_%s' % (lname, tag)] = x.grad.numpy().copy()
+    save('losses', **arrs)
+
+
+if __name__ == '__main__':
+    main()

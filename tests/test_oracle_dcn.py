@@ -1,0 +1,93 @@
+"""Pins the CPU oracle of the DCN operator (oracle/dcn_oracle.{c,py}); CPU only.
+
+The reference has no tests/golden vectors for this operator, so the
+oracle is pinned by known-answer identities and float64 finite differences, plus determinism
+against the committed fixture generated through the imported reference Pack wiring."""
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_err
+from oracle.dcn_oracle import modulated_deform_conv
+
+
+def _rand(B=2, C=8, Co=6, dg=2, H=6, W=7, dtype=torch.float32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g, dtype=dtype)
+    w = torch.randn(Co, C, 3, 3, generator=g, dtype=dtype)
+    b = torch.randn(Co, generator=g, dtype=dtype)
+    return x, w, b, dg
+
+
+def test_zero_offset_unit_mask_is_conv2d():
+    x, w, b, dg = _rand()
+    off = torch.zeros(2, dg * 18, 6, 7)
+    m = torch.ones(2, dg * 9, 6, 7)
+    out = modulated_deform_conv(x, off, m, w, b, 1, 1, 1, 1, dg)
+    assert rel_err(out, F.conv2d(x, w, b, padding=1)) < 1e-6
+
+
+def test_half_mask_scales_conv():  # zero-initialised conv_offset_mask => sigmoid(0) = 0.5
+    x, w, b, dg = _rand(seed=1)
+    off = torch.zeros(2, dg * 18, 6, 7)
+    m = torch.full((2, dg * 9, 6, 7), 0.5)
+    out = modulated_deform_conv(x, off, m, w, b, 1, 1, 1, 1, dg)
+    assert rel_err(out, 0.5 * F.conv2d(x, w, None, padding=1) + b.view(1, -1, 1, 1)) < 1e-6
+
+
+def test_integer_offsets_shift_the_input():
+    x, w, b, dg = _rand(seed=2)
+    off = torch.zeros(2, dg * 18, 6, 7)
+    off[:, 0::2] = 1.0   # dy = +1
+    off[:, 1::2] = -2.0  # dx = -2
+    m = torch.ones(2, dg * 9, 6, 7)
+    out = modulated_deform_conv(x, off, m, w, b, 1, 1, 1, 1, dg)
+    shifted = torch.zeros_like(x)  # shifted[h, w] = x[h+1, w-2], zero outside
+    shifted[:, :, :-1, 2:] = x[:, :, 1:, :-2]
+    # rows/cols whose zero-PADDING taps map to valid shifted samples differ by construction
+    assert rel_err(out[:, :, 1:, :-1], F.conv2d(shifted, w, b, padding=1)[:, :, 1:, :-1]) < 1e-6
+
+
+def test_zero_mask_and_far_offsets_give_bias():
+    x, w, b, dg = _rand(seed=3)
+    off = torch.zeros(2, dg * 18, 6, 7)
+    out = modulated_deform_conv(x, off, torch.zeros(2, dg * 9, 6, 7), w, b, 1, 1, 1, 1, dg)
+    assert torch.equal(out, b.view(1, -1, 1, 1).expand_as(out).contiguous())
+    out = modulated_deform_conv(x, off + 100.0, torch.ones(2, dg * 9, 6, 7), w, b, 1, 1, 1, 1, dg)
+    assert torch.equal(out, b.view(1, -1, 1, 1).expand_as(out).contiguous())
+
+
+def test_stride_dilation_match_conv2d():
+    x, w, b, dg = _rand(H=9, W=11, seed=4)
+    for stride, pad, dil in [(2, 1, 1), (1, 2, 2), (2, 0, 1)]:
+        ref = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+        Ho, Wo = ref.shape[2:]
+        out = modulated_deform_conv(x, torch.zeros(2, dg * 18, Ho, Wo), torch.ones(2, dg * 9, Ho, Wo),
+                                    w, b, stride, pad, dil, 1, dg)
+        assert rel_err(out, ref) < 1e-6
+
+
+def test_f64_finite_differences():
+    g = torch.Generator().manual_seed(5)
+    B, C, Co, dg, H, W = 1, 4, 3, 2, 4, 5
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    # keep sample positions away from the integer lattice (the operator is only piecewise smooth)
+    off = (torch.rand(B, dg * 18, H, W, generator=g, dtype=torch.float64) * 0.6 + 0.2)
+    off = off * torch.where(torch.rand(off.shape, generator=g) > 0.5, 1.0, -1.0) + \
+        torch.randint(-2, 3, off.shape, generator=g).double()
+    off.requires_grad_(True)
+    m = torch.rand(B, dg * 9, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, C, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(Co, generator=g, dtype=torch.float64, requires_grad=True)
+    fn = lambda *a: modulated_deform_conv(*a, 1, 1, 1, 1, dg)  # noqa: E731
+    assert torch.autograd.gradcheck(fn, (x, off, m, w, b), eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
+def test_matches_committed_fixture():
+    g = load_golden('dcn_op')
+    t = {k: torch.from_numpy(v) for k, v in g.items() if v.ndim > 0}
+    leaves = [t[k].clone().requires_grad_(True) for k in ('x', 'offset', 'mask', 'weight', 'bias')]
+    out = modulated_deform_conv(*leaves, 1, 1, 1, 1, int(g['dg']))
+    out.backward(t['gout'])
+    assert rel_err(out, t['out']) < 1e-6
+    for leaf, key in zip(leaves, ('gx', 'goffset', 'gmask', 'gweight', 'gbias')):
+        assert rel_err(leaf.grad, t[key]) < 2e-6, key
