@@ -1,0 +1,80 @@
+"""ctypes binding of librealvsr_hip.so (C ABI: include/realvsr_hip.h).
+
+The library is built in-tree (``realvsr_amd/csrc/librealvsr_hip.so``) by ``build()`` /
+``__graft_entry__.build()``.  If it is missing the product fails loudly: there is no fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+SO_PATH = os.path.join(_CSRC, 'librealvsr_hip.so')
+_lib = None
+
+c_fp = ctypes.c_void_p  # device pointers travel as void*
+c_int, c_float, c_double, c_size = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/realvsr_hip.h
+SIGNATURES = {
+    'rvsr_last_error': (ctypes.c_char_p, []),
+    'rvsr_modulated_deform_conv_forward': (c_int, [c_fp] * 6 + [c_int] * 16 + [c_fp]),
+    'rvsr_modulated_deform_conv_backward_workspace_bytes': (c_size, [c_int] * 8),
+    'rvsr_modulated_deform_conv_backward': (c_int, [c_fp] * 11 + [c_int] * 16 + [c_fp, c_size, c_fp]),
+    'rvsr_dcn_pack_forward': (c_int, [c_fp] * 5 + [c_int] * 10 + [c_float, c_fp]),
+    'rvsr_dcn_pack_backward': (c_int, [c_fp] * 5 + [c_float] + [c_fp] * 4 + [c_int] * 9 + [c_fp, c_size, c_fp]),
+    'rvsr_conv2d_forward': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_float, c_int, c_int, c_int, c_fp, c_fp, c_fp,
+                                    c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                    c_int, c_int, c_fp]),
+    'rvsr_conv2d_wgrad_workspace_bytes': (c_size, [c_int] * 8),
+    'rvsr_conv2d_backward_weight': (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_float, c_int, c_int,
+                                            c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
+                                            c_size, c_fp]),
+    'rvsr_upsample_bilinear_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_int, c_float, c_fp]),
+    'rvsr_upsample_bilinear_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_int, c_float, c_fp]),
+    'rvsr_maxavgpool_forward': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    'rvsr_maxavgpool_backward': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    'rvsr_tsa_temporal_forward': (c_int, [c_fp] * 5 + [c_int] * 5 + [c_fp]),
+    'rvsr_tsa_temporal_backward': (c_int, [c_fp] * 8 + [c_int] * 5 + [c_fp]),
+    'rvsr_tsa_output_forward': (c_int, [c_fp] * 4 + [c_size, c_fp]),
+    'rvsr_tsa_output_backward': (c_int, [c_fp] * 5 + [c_size, c_fp]),
+    'rvsr_pyr_down_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_pyr_down_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_pyr_updiff_forward': (c_int, [c_fp, c_fp, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_pyr_updiff_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_charbonnier_workspace_bytes': (c_size, []),
+    'rvsr_charbonnier_forward': (c_int, [c_fp, c_fp, c_size, c_float, c_double, c_fp, c_fp, c_fp]),
+    'rvsr_charbonnier_backward': (c_int, [c_fp, c_fp, c_fp, c_float, c_float, c_fp, c_size, c_fp]),
+}
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into csrc/librealvsr_hip.so (hipcc cross-compiles
+    without a GPU)."""
+    cmd = ['make', '-C', _CSRC, '-j4'] + ([] if verbose else ['-s'])
+    subprocess.check_call(cmd)
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError('build did not produce %s' % SO_PATH)
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                'realvsr_amd: %s is missing -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C realvsr_amd/csrc`).  There is no CPU / eager fallback.' % SO_PATH)
+        import torch  # noqa: F401  (loads libamdhip64 the .so links against)
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().rvsr_last_error()
+        raise RuntimeError('%s failed (code %d): %s' % (what, rc, msg.decode() if msg else ''))

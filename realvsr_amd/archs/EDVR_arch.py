@@ -1,0 +1,213 @@
+"""EDVR on MI355X: PCD_Align, TSA_Fusion, EDVR, EDVR_NoUp with the reference's constructor
+arguments, forward signature and state_dict schema (codes/models/archs/EDVR_arch.py:62-404).
+
+nn.Conv2d modules are kept as parameter holders (names + default init = reference); the compute
+is the fused HIP operators of realvsr_amd.functional:
+  * every conv + bias + (Leaky)ReLU (+ residual) is one kernel, torch.cat inputs are passed as
+    two pointers, ``F.interpolate(...) * 2`` is one kernel, PixelShuffle is folded into the conv;
+  * each DCN pack = one conv kernel + one fused DCN kernel (LeakyReLU in its epilogue);
+  * TSA's correlation / sigmoid / modulation and its output gate are one kernel each.
+The optional ``predeblur`` / ``HR_in`` branches (EDVR_arch.py:224-231,264-274) are enabled by no
+shipped config and are not built: requesting them raises.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+
+from . import arch_util
+from .dcn import ModulatedDeformConvPack as DCN
+from .. import functional as RF
+
+LRELU = RF.ACT_LRELU
+
+
+class PCD_Align(nn.Module):
+    """Alignment module using Pyramid, Cascading and Deformable convolution, 3 pyramid levels."""
+
+    def __init__(self, nf=64, groups=8):
+        super(PCD_Align, self).__init__()
+        # L3: level 3, 1/4 spatial size
+        self.L3_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
+        self.L3_offset_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.L3_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
+                              extra_offset_mask=True)
+        # L2: level 2, 1/2 spatial size
+        self.L2_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
+        self.L2_offset_conv2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for offset
+        self.L2_offset_conv3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.L2_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
+                              extra_offset_mask=True)
+        self.L2_fea_conv = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for fea
+        # L1: level 1, original spatial size
+        self.L1_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
+        self.L1_offset_conv2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for offset
+        self.L1_offset_conv3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.L1_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
+                              extra_offset_mask=True)
+        self.L1_fea_conv = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for fea
+        # Cascading DCN
+        self.cas_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
+        self.cas_offset_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.cas_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
+                               extra_offset_mask=True)
+
+    def forward(self, nbr_fea_l, ref_fea_l):
+        """nbr_fea_l, ref_fea_l: [L1, L2, L3], each with [B,C,H,W] features"""
+        conv, up = RF.conv2d, RF.upsample_bilinear
+        # L3
+        L3_offset = conv(nbr_fea_l[2], self.L3_offset_conv1, LRELU, x2=ref_fea_l[2])
+        L3_offset = conv(L3_offset, self.L3_offset_conv2, LRELU)
+        L3_fea = self.L3_dcnpack([nbr_fea_l[2], L3_offset], act=LRELU)
+        # L2
+        L2_offset = conv(nbr_fea_l[1], self.L2_offset_conv1, LRELU, x2=ref_fea_l[1])
+        L2_offset = conv(L2_offset, self.L2_offset_conv2, LRELU, x2=up(L3_offset, 2, 2.0))
+        L2_offset = conv(L2_offset, self.L2_offset_conv3, LRELU)
+        L2_fea = self.L2_dcnpack([nbr_fea_l[1], L2_offset])
+        L2_fea = conv(L2_fea, self.L2_fea_conv, LRELU, x2=up(L3_fea, 2))
+        # L1
+        L1_offset = conv(nbr_fea_l[0], self.L1_offset_conv1, LRELU, x2=ref_fea_l[0])
+        L1_offset = conv(L1_offset, self.L1_offset_conv2, LRELU, x2=up(L2_offset, 2, 2.0))
+        L1_offset = conv(L1_offset, self.L1_offset_conv3, LRELU)
+        L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset])
+        L1_fea = conv(L1_fea, self.L1_fea_conv, x2=up(L2_fea, 2))  # no activation (EDVR_arch.py:125)
+        # Cascading
+        offset = conv(L1_fea, self.cas_offset_conv1, LRELU, x2=ref_fea_l[0])
+        offset = conv(offset, self.cas_offset_conv2, LRELU)
+        return self.cas_dcnpack([L1_fea, offset], act=LRELU)
+
+
+class TSA_Fusion(nn.Module):
+    """Temporal Spatial Attention fusion module. Temporal: correlation; Spatial: 3 pyramid levels."""
+
+    def __init__(self, nf=64, nframes=5, center=2):
+        super(TSA_Fusion, self).__init__()
+        self.center = center
+        # temporal attention (before fusion conv)
+        self.tAtt_1 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.tAtt_2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        # fusion conv: using 1x1 to save parameters and computation
+        self.fea_fusion = nn.Conv2d(nframes * nf, nf, 1, 1, bias=True)
+        # spatial attention (after fusion conv)
+        self.sAtt_1 = nn.Conv2d(nframes * nf, nf, 1, 1, bias=True)
+        self.sAtt_2 = nn.Conv2d(nf * 2, nf, 1, 1, bias=True)
+        self.sAtt_3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.sAtt_4 = nn.Conv2d(nf, nf, 1, 1, bias=True)
+        self.sAtt_5 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.sAtt_L1 = nn.Conv2d(nf, nf, 1, 1, bias=True)
+        self.sAtt_L2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
+        self.sAtt_L3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.sAtt_add_1 = nn.Conv2d(nf, nf, 1, 1, bias=True)
+        self.sAtt_add_2 = nn.Conv2d(nf, nf, 1, 1, bias=True)
+
+    def forward(self, aligned_fea):
+        conv, up = RF.conv2d, RF.upsample_bilinear
+        B, N, C, H, W = aligned_fea.size()  # N video frames
+        aligned_fea = aligned_fea.contiguous()
+        #### temporal attention
+        emb_ref = conv(aligned_fea[:, self.center], self.tAtt_2)
+        emb = conv(aligned_fea.view(-1, C, H, W), self.tAtt_1).view(B, N, -1, H, W)
+        aligned_fea = RF.tsa_temporal(emb, emb_ref, aligned_fea)  # [B, N*C, H, W]
+        #### fusion
+        fea = conv(aligned_fea, self.fea_fusion, LRELU)
+        #### spatial attention
+        att = conv(aligned_fea, self.sAtt_1, LRELU)
+        att = conv(RF.maxavgpool(att), self.sAtt_2, LRELU)
+        # pyramid levels
+        att_L = conv(att, self.sAtt_L1, LRELU)
+        att_L = conv(RF.maxavgpool(att_L), self.sAtt_L2, LRELU)
+        att_L = up(conv(att_L, self.sAtt_L3, LRELU), 2)
+        att = conv(att, self.sAtt_3, LRELU, residual=att_L)
+        att = up(conv(att, self.sAtt_4, LRELU), 2)
+        att = conv(att, self.sAtt_5)
+        att_add = conv(conv(att, self.sAtt_add_1, LRELU), self.sAtt_add_2)
+        return RF.tsa_output(fea, att, att_add)
+
+
+class _EDVRBase(nn.Module):
+    upscale = True
+
+    def __init__(self, nf=64, nc=3, nframes=5, groups=8, front_RBs=5, back_RBs=10, center=None, predeblur=False,
+                 HR_in=False, w_TSA=True):
+        super(_EDVRBase, self).__init__()
+        if predeblur or HR_in:
+            raise NotImplementedError('predeblur / HR_in branches are used by no shipped RealVSR config and are '
+                                      'not part of the MI355X hot path')
+        self.nf = nf
+        self.nc = nc
+        self.center = nframes // 2 if center is None else center
+        self.is_predeblur = False
+        self.HR_in = False
+        self.w_TSA = w_TSA
+        ResidualBlock_noBN_f = functools.partial(arch_util.ResidualBlock_noBN, nf=nf)
+        #### extract features (for each frame)
+        self.conv_first = nn.Conv2d(nc, nf, 3, 1, 1, bias=True)
+        self.feature_extraction = arch_util.make_layer(ResidualBlock_noBN_f, front_RBs)
+        self.fea_L2_conv1 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+        self.fea_L2_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.fea_L3_conv1 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+        self.fea_L3_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
+        self.pcd_align = PCD_Align(nf=nf, groups=groups)
+        if self.w_TSA:
+            self.tsa_fusion = TSA_Fusion(nf=nf, nframes=nframes, center=self.center)
+        else:
+            self.tsa_fusion = nn.Conv2d(nframes * nf, nf, 1, 1, bias=True)
+        #### reconstruction
+        self.recon_trunk = arch_util.make_layer(ResidualBlock_noBN_f, back_RBs)
+        if self.upscale:
+            self.upconv1 = nn.Conv2d(nf, nf * 4, 3, 1, 1, bias=True)
+            self.upconv2 = nn.Conv2d(nf, 64 * 4, 3, 1, 1, bias=True)
+            self.pixel_shuffle = nn.PixelShuffle(2)
+        self.HRconv = nn.Conv2d(64, 64, 3, 1, 1, bias=True)
+        self.conv_last = nn.Conv2d(64, nc, 3, 1, 1, bias=True)
+
+    def forward(self, x):
+        conv = RF.conv2d
+        B, N, C, H, W = x.size()  # N video frames
+        if H % 4 or W % 4:
+            raise RuntimeError('EDVR needs H and W divisible by 4 (got %dx%d)' % (H, W))
+        x = x.contiguous()
+        x_center = x[:, self.center, :, :, :].contiguous()
+        #### extract LR features
+        L1_fea = conv(x.view(-1, C, H, W), self.conv_first, LRELU)
+        L1_fea = self.feature_extraction(L1_fea)
+        L2_fea = conv(L1_fea, self.fea_L2_conv1, LRELU)
+        L2_fea = conv(L2_fea, self.fea_L2_conv2, LRELU)
+        L3_fea = conv(L2_fea, self.fea_L3_conv1, LRELU)
+        L3_fea = conv(L3_fea, self.fea_L3_conv2, LRELU)
+        L1_fea = L1_fea.view(B, N, -1, H, W)
+        L2_fea = L2_fea.view(B, N, -1, H // 2, W // 2)
+        L3_fea = L3_fea.view(B, N, -1, H // 4, W // 4)
+        #### pcd align
+        ref_fea_l = [L1_fea[:, self.center].contiguous(), L2_fea[:, self.center].contiguous(),
+                     L3_fea[:, self.center].contiguous()]
+        aligned_fea = []
+        for i in range(N):
+            nbr_fea_l = [L1_fea[:, i].contiguous(), L2_fea[:, i].contiguous(), L3_fea[:, i].contiguous()]
+            aligned_fea.append(self.pcd_align(nbr_fea_l, ref_fea_l))
+        aligned_fea = torch.stack(aligned_fea, dim=1)  # [B, N, C, H, W]
+        if self.w_TSA:
+            fea = self.tsa_fusion(aligned_fea)
+        else:
+            fea = conv(aligned_fea.view(B, -1, H, W), self.tsa_fusion)
+        out = self.recon_trunk(fea)
+        if self.upscale:
+            out = conv(out, self.upconv1, LRELU, pixel_shuffle=True)
+            out = conv(out, self.upconv2, LRELU, pixel_shuffle=True)
+            out = conv(out, self.HRconv, LRELU)
+            base = RF.upsample_bilinear(x_center, 4)
+        else:
+            out = conv(out, self.HRconv, LRELU)
+            base = x_center
+        return conv(out, self.conv_last, residual=base)
+
+
+class EDVR(_EDVRBase):
+    """EDVR with x4 upsampling tail (EDVR_arch.py:211-320)."""
+    upscale = True
+
+
+class EDVR_NoUp(_EDVRBase):
+    """EDVR without upsampling -- the variant RealVSR trains (EDVR_arch.py:323-404); as in the
+    reference it only works for nf=64 (HRconv is hard-coded 64->64, :352)."""
+    upscale = False

@@ -1,0 +1,141 @@
+"""Drop-in for codes/models/archs/dcn/deform_conv.py on MI355X.
+
+Same public names, constructor arguments, parameter names (``weight``, ``bias``,
+``conv_offset_mask.{weight,bias}``) and initialisation as the reference, so reference
+checkpoints load with ``strict=True``.  The arithmetic runs in librealvsr_hip.so
+(realvsr_amd/csrc/dcn_kernels.hip) through the C ABI in include/realvsr_hip.h.
+
+* ``modulated_deform_conv`` / ``ModulatedDeformConv``: the dense-offset operator
+  (deform_conv.py:97-153, 228-254) -> rvsr_modulated_deform_conv_{forward,backward}.
+* ``ModulatedDeformConvPack`` (deform_conv.py:257-292): conv_offset_mask runs as a fused conv
+  kernel and the DCN consumes its raw 3*dg*9-channel output directly (chunk / cat / sigmoid are
+  addressing + an in-kernel sigmoid) -> rvsr_dcn_pack_{forward,backward}.  ``act`` lets the
+  caller fuse the LeakyReLU that follows the pack in PCD_Align (EDVR_arch.py:107,130).
+* DCNv1 (``deform_conv`` / ``DeformConv`` / ``DeformConvPack``, deform_conv.py:15-95,156-226):
+  imported by no architecture in the reference; the names exist for API
+  parity and raise NotImplementedError when called -- there is no silent fallback.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+
+from ... import functional as RF
+from ...functional import ModulatedDeformConvFunction, modulated_deform_conv
+
+
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+    if input is not None and input.dim() != 4:
+        raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
+    raise NotImplementedError('DCNv1 (deform_conv) is outside the MI355X hot path: no architecture of the '
+                              'reference uses it; use modulated_deform_conv')
+
+
+class DeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super(DeformConv, self).__init__()
+        assert not bias
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        stdv = 1. / math.sqrt(in_channels * self.kernel_size[0] * self.kernel_size[1])
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
+
+
+class DeformConvPack(DeformConv):
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels,
+                                     self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                     padding=_pair(self.padding), bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        return deform_conv(x, None, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
+
+
+class ModulatedDeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super(ModulatedDeformConv, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):  # deform_conv.py:242-249
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                     self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+    def __init__(self, *args, extra_offset_mask=False, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+        self.extra_offset_mask = extra_offset_mask
+        self.conv_offset_mask = nn.Conv2d(self.in_channels,
+                                          self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+                                          kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                          padding=_pair(self.padding), bias=True)
+        self.init_offset()
+
+    def init_offset(self):  # deform_conv.py:270-272
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def forward(self, x, act=RF.ACT_NONE, slope=0.1):
+        if self.extra_offset_mask:  # x = [input, features]
+            x, feat = x[0], x[1]
+        else:
+            feat = x
+        fused = (self.kernel_size == (3, 3) and self.groups == 1 and
+                 self.padding == self.dilation * (self.kernel_size[0] // 2))
+        if fused:
+            om = RF.conv2d(feat, self.conv_offset_mask)
+            return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                               self.deformable_groups, act, slope)
+        # general geometry: explicit chunk / cat / sigmoid, dense-offset operator
+        out = torch.nn.functional.conv2d(feat, self.conv_offset_mask.weight, self.conv_offset_mask.bias,
+                                         self.conv_offset_mask.stride, self.conv_offset_mask.padding)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        out = modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                    self.dilation, self.groups, self.deformable_groups)
+        if act == RF.ACT_RELU:
+            out = torch.relu(out)
+        elif act == RF.ACT_LRELU:
+            out = torch.nn.functional.leaky_relu(out, slope)
+        return out

@@ -1,0 +1,440 @@
+"""Autograd glue between PyTorch tensors and the C ABI of librealvsr_hip.so.
+
+PyTorch is used for device memory, streams and the autograd graph only; every FLOP of the hot
+path runs in the HIP kernels (realvsr_amd/csrc).  Each ``Function`` below wraps one fused
+operator; CPU tensors are refused (NotImplementedError, like the reference's operator:
+codes/models/archs/dcn/deform_conv.py:109-110,124-125).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise NotImplementedError('realvsr_amd operators run on MI355X (HIP) tensors only; got a %s tensor'
+                                      % t.device.type)
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError('realvsr_amd operators are float32 (like the reference training path); got %s' % t.dtype)
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    """Per-(device, stream) scratch buffer, grown on demand (kernels on one stream are ordered,
+    so consecutive operators can share it)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ conv
+class _Conv2dFused(Function):
+    """act(conv2d(cat(x1, x2), w) + b) [+ residual] [-> PixelShuffle(2)]"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle):
+        _need_cuda(x1, x2, weight, bias, residual)
+        x1, x2, weight, bias, residual = _c(x1), _c(x2), _c(weight), _c(bias), _c(residual)
+        B, C1, H, W = x1.shape
+        C2 = 0 if x2 is None else x2.shape[1]
+        Co, Cw, k, _ = weight.shape
+        if Cw != C1 + C2:
+            raise RuntimeError('conv2d: weight expects %d input channels, got %d' % (Cw, C1 + C2))
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        if pixel_shuffle:
+            out = x1.new_empty(B, Co // 4, 2 * Ho, 2 * Wo)
+        else:
+            out = x1.new_empty(B, Co, Ho, Wo)
+        L = _lib.lib()
+        _lib.check(L.rvsr_conv2d_forward(_p(x1), C1, _p(x2), C2, None, 0.0, 0, H, W, _p(weight), _p(bias),
+                                         _p(residual), _p(out), Co, None, 0, B, k, stride, 0, act, slope,
+                                         int(pixel_shuffle), Ho, Wo, _stream()), 'conv2d_forward')
+        ctx.cfg = (stride, act, slope, bool(pixel_shuffle), C1, C2, H, W, Ho, Wo, k, bias is not None,
+                   residual is not None)
+        ctx.save_for_backward(x1, x2, weight, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x1, x2, weight, act_out = ctx.saved_tensors
+        stride, act, slope, ps, C1, C2, H, W, Ho, Wo, k, has_bias, has_res = ctx.cfg
+        gout = gout.contiguous()
+        B, Co = x1.shape[0], weight.shape[0]
+        L = _lib.lib()
+        gslope = 0.0 if act == ACT_RELU else slope
+        need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gx1 = gx2 = gw = gb = None
+        if need_x1 or (x2 is not None and need_x2):
+            gx1 = torch.empty_like(x1)
+            gx2 = torch.empty_like(x2) if x2 is not None else None
+            in_mode = 2 if ps else (1 if stride == 2 else 0)
+            _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2],
+                                             gout.shape[3], _p(weight), None, None, _p(gx1), C1, _p(gx2), C2, B, k,
+                                             1, 1, ACT_NONE, 0.0, 0, H, W, _stream()), 'conv2d_backward_data')
+        if need_w or (has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty_like(weight)
+            gb = weight.new_empty(Co) if has_bias else None
+            nbytes = L.rvsr_conv2d_wgrad_workspace_bytes(C1, C2, Co, B, k, stride, Ho, Wo)
+            ws = _workspace(nbytes, x1.device)
+            _lib.check(L.rvsr_conv2d_backward_weight(_p(x1), C1, _p(x2), C2, H, W, _p(gout), _p(act_out), gslope,
+                                                     2 if ps else 0, gout.shape[2], gout.shape[3], _p(gw), _p(gb),
+                                                     Co, B, k, stride, Ho, Wo, 0, _p(ws), ws.numel(), _stream()),
+                       'conv2d_backward_weight')
+        gres = gout if has_res else None
+        return gx1, gx2, gw, gb, gres, None, None, None, None
+
+
+def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False):
+    """Fused conv block driven by an ``nn.Conv2d`` parameter holder (weight, bias, stride).
+
+    out = act(conv(cat(x, x2))) [+ residual]; with ``pixel_shuffle`` the activation commutes with
+    the shuffle, so lrelu(pixel_shuffle(conv(x))) (EDVR_arch.py:311-312) is one kernel."""
+    stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
+    if residual is not None and act != ACT_NONE:
+        # act'(.) is recovered from the saved activation output, so the residual is added outside
+        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle)
+        return out + residual
+    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle)
+
+
+# ------------------------------------------------------------------------------------------ DCN
+class ModulatedDeformConvFunction(Function):
+    """Same signature and semantics as the reference's autograd Function
+    (codes/models/archs/dcn/deform_conv.py:97-153)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                deformable_groups=1):
+        if not input.is_cuda:
+            raise NotImplementedError
+        _need_cuda(input, offset, mask, weight, bias)
+        if not input.is_contiguous():
+            raise RuntimeError('input tensor has to be contiguous')      # deform_conv_cuda.cpp:497
+        if not weight.is_contiguous():
+            raise RuntimeError('weight tensor has to be contiguous')     # deform_conv_cuda.cpp:498
+        offset, mask = offset.contiguous(), mask.contiguous()
+        ctx.cfg = (stride, padding, dilation, groups, deformable_groups, bias is not None)
+        B, C, H, W = input.shape
+        Co, _, kh, kw = weight.shape
+        Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+        output = input.new_empty(B, Co, Ho, Wo)
+        L = _lib.lib()
+        _lib.check(L.rvsr_modulated_deform_conv_forward(
+            _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(output), B, C, H, W, Co, kh, kw, stride, stride,
+            padding, padding, dilation, dilation, groups, deformable_groups, int(bias is not None), _stream()),
+            'modulated_deform_conv_forward')
+        ctx.save_for_backward(input, offset, mask, weight, bias)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        stride, padding, dilation, groups, dg, with_bias = ctx.cfg
+        grad_output = grad_output.contiguous()
+        B, C, H, W = input.shape
+        Co, _, kh, kw = weight.shape
+        grad_input = torch.zeros_like(input)
+        grad_offset = torch.empty_like(offset)
+        grad_mask = torch.empty_like(mask)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias) if with_bias else None
+        L = _lib.lib()
+        nbytes = L.rvsr_modulated_deform_conv_backward_workspace_bytes(B, C, H, W, Co, stride, padding, dilation)
+        ws = _workspace(nbytes, input.device)
+        _lib.check(L.rvsr_modulated_deform_conv_backward(
+            _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(grad_input), _p(grad_weight), _p(grad_bias),
+            _p(grad_offset), _p(grad_mask), _p(grad_output), B, C, H, W, Co, kh, kw, stride, stride, padding, padding,
+            dilation, dilation, groups, dg, int(with_bias), _p(ws), ws.numel(), _stream()),
+            'modulated_deform_conv_backward')
+        return grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None, None
+
+
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class _DcnPackFused(Function):
+    """DCN fed directly by the raw conv_offset_mask output (chunk/cat/sigmoid fused)."""
+
+    @staticmethod
+    def forward(ctx, x, om, weight, bias, stride, padding, dilation, dg, act, slope):
+        _need_cuda(x, om, weight, bias)
+        x, om, weight, bias = _c(x), _c(om), _c(weight), _c(bias)
+        B, C, H, W = x.shape
+        Co = weight.shape[0]
+        if weight.shape[2:] != (3, 3):
+            raise RuntimeError('fused DCN pack supports 3x3 kernels')
+        Ho = (H + 2 * padding - (dilation * 2 + 1)) // stride + 1
+        Wo = (W + 2 * padding - (dilation * 2 + 1)) // stride + 1
+        if tuple(om.shape) != (B, 27 * dg, Ho, Wo):
+            raise RuntimeError('conv_offset_mask output has shape %s, expected %s' % (tuple(om.shape), (B, 27 * dg, Ho, Wo)))
+        out = x.new_empty(B, Co, Ho, Wo)
+        L = _lib.lib()
+        _lib.check(L.rvsr_dcn_pack_forward(_p(x), _p(weight), _p(bias), _p(om), _p(out), B, C, H, W, Co, stride,
+                                           padding, dilation, dg, act, slope, _stream()), 'dcn_pack_forward')
+        ctx.cfg = (stride, padding, dilation, dg, act, slope, bias is not None)
+        ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, om, weight, act_out = ctx.saved_tensors
+        stride, padding, dilation, dg, act, slope, has_bias = ctx.cfg
+        gout = gout.contiguous()
+        B, C, H, W = x.shape
+        Co = weight.shape[0]
+        gx = torch.zeros_like(x)
+        gom = torch.empty_like(om)
+        gw = torch.zeros_like(weight)
+        gb = weight.new_zeros(Co) if has_bias else None
+        L = _lib.lib()
+        nbytes = L.rvsr_modulated_deform_conv_backward_workspace_bytes(B, C, H, W, Co, stride, padding, dilation)
+        ws = _workspace(nbytes, x.device)
+        gslope = 0.0 if act == ACT_RELU else slope
+        _lib.check(L.rvsr_dcn_pack_backward(_p(x), _p(weight), _p(om), _p(gout), _p(act_out), gslope, _p(gx), _p(gw),
+                                            _p(gb), _p(gom), B, C, H, W, Co, stride, padding, dilation, dg, _p(ws),
+                                            ws.numel(), _stream()), 'dcn_pack_backward')
+        return gx, gom, gw, gb, None, None, None, None, None, None
+
+
+def dcn_pack(x, om, weight, bias, stride, padding, dilation, deformable_groups, act=ACT_NONE, slope=0.1):
+    return _DcnPackFused.apply(x, om, weight, bias, stride, padding, dilation, deformable_groups, act, slope)
+
+
+# ------------------------------------------------------------------------------------------ resampling / fusion
+class _UpsampleBilinear(Function):
+    @staticmethod
+    def forward(ctx, x, factor, scale):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = x.new_empty(B, C, H * factor, W * factor)
+        _lib.check(_lib.lib().rvsr_upsample_bilinear_forward(_p(x), _p(out), B * C, H, W, factor, scale, _stream()),
+                   'upsample_bilinear_forward')
+        ctx.cfg = (factor, scale, B, C, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        factor, scale, B, C, H, W = ctx.cfg
+        gout = gout.contiguous()
+        gin = gout.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().rvsr_upsample_bilinear_backward(_p(gout), _p(gin), B * C, H, W, factor, scale, _stream()),
+                   'upsample_bilinear_backward')
+        return gin, None, None
+
+
+def upsample_bilinear(x, factor=2, scale=1.0):
+    """scale * F.interpolate(x, scale_factor=factor, mode='bilinear', align_corners=False)"""
+    return _UpsampleBilinear.apply(x, factor, float(scale))
+
+
+class _MaxAvgPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = x.new_empty(B, 2 * C, Ho, Wo)
+        arg = torch.empty(B, C, Ho, Wo, dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().rvsr_maxavgpool_forward(_p(x), _p(out), _p(arg), B, C, H, W, _stream()), 'maxavgpool_forward')
+        ctx.cfg = (B, C, H, W)
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (arg,) = ctx.saved_tensors
+        B, C, H, W = ctx.cfg
+        gout = gout.contiguous()
+        gin = gout.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().rvsr_maxavgpool_backward(_p(gout), _p(arg), _p(gin), B, C, H, W, _stream()),
+                   'maxavgpool_backward')
+        return gin
+
+
+def maxavgpool(x):
+    """cat([max_pool2d(x, 3, 2, 1), avg_pool2d(x, 3, 2, 1)], 1)"""
+    return _MaxAvgPool.apply(x)
+
+
+class _TSATemporal(Function):
+    @staticmethod
+    def forward(ctx, emb, emb_ref, aligned):
+        _need_cuda(emb, emb_ref, aligned)
+        emb, emb_ref, aligned = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous()
+        B, N, C, H, W = aligned.shape
+        mod = aligned.new_empty(B, N * C, H, W)
+        prob = aligned.new_empty(B, N, H, W)
+        _lib.check(_lib.lib().rvsr_tsa_temporal_forward(_p(emb), _p(emb_ref), _p(aligned), _p(mod), _p(prob), B, N, C,
+                                                        H, W, _stream()), 'tsa_temporal_forward')
+        ctx.save_for_backward(emb, emb_ref, aligned, prob)
+        return mod
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gmod):
+        emb, emb_ref, aligned, prob = ctx.saved_tensors
+        B, N, C, H, W = aligned.shape
+        gmod = gmod.contiguous()
+        galigned, gemb, gemb_ref = torch.empty_like(aligned), torch.empty_like(emb), torch.empty_like(emb_ref)
+        _lib.check(_lib.lib().rvsr_tsa_temporal_backward(_p(gmod), _p(emb), _p(emb_ref), _p(aligned), _p(prob),
+                                                         _p(galigned), _p(gemb), _p(gemb_ref), B, N, C, H, W,
+                                                         _stream()), 'tsa_temporal_backward')
+        return gemb, gemb_ref, galigned
+
+
+def tsa_temporal(emb, emb_ref, aligned):
+    """aligned * sigmoid(sum_c emb * emb_ref), returned as (B, N*C, H, W)"""
+    return _TSATemporal.apply(emb, emb_ref, aligned)
+
+
+class _TSAOutput(Function):
+    @staticmethod
+    def forward(ctx, fea, att, att_add):
+        _need_cuda(fea, att, att_add)
+        fea, att, att_add = fea.contiguous(), att.contiguous(), att_add.contiguous()
+        out = torch.empty_like(fea)
+        _lib.check(_lib.lib().rvsr_tsa_output_forward(_p(fea), _p(att), _p(att_add), _p(out), fea.numel(), _stream()),
+                   'tsa_output_forward')
+        ctx.save_for_backward(fea, att)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        fea, att = ctx.saved_tensors
+        g = g.contiguous()
+        gfea, gatt = torch.empty_like(fea), torch.empty_like(att)
+        _lib.check(_lib.lib().rvsr_tsa_output_backward(_p(g), _p(fea), _p(att), _p(gfea), _p(gatt), fea.numel(),
+                                                       _stream()), 'tsa_output_backward')
+        return gfea, gatt, g
+
+
+def tsa_output(fea, att, att_add):
+    """fea * sigmoid(att) * 2 + att_add"""
+    return _TSAOutput.apply(fea, att, att_add)
+
+
+# ------------------------------------------------------------------------------------------ pyramid / loss
+class _PyrDown(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = x.new_empty(B, C, (H + 1) // 2, (W + 1) // 2)
+        _lib.check(_lib.lib().rvsr_pyr_down_forward(_p(x), _p(out), B * C, H, W, _stream()), 'pyr_down_forward')
+        ctx.cfg = (B, C, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        B, C, H, W = ctx.cfg
+        gout = gout.contiguous()
+        gin = gout.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().rvsr_pyr_down_backward(_p(gout), _p(gin), B * C, H, W, _stream()), 'pyr_down_backward')
+        return gin
+
+
+def pyr_down(x):
+    """downsample(conv_gauss(x, gauss_kernel)) (utils/util.py:503-510)"""
+    return _PyrDown.apply(x)
+
+
+class _PyrUpDiff(Function):
+    @staticmethod
+    def forward(ctx, cur, down):
+        _need_cuda(cur, down)
+        cur, down = cur.contiguous(), down.contiguous()
+        B, C, H, W = cur.shape
+        if tuple(down.shape) != (B, C, H // 2, W // 2) or H % 2 or W % 2:
+            # same failure the reference hits as a shape mismatch in `current - up` (utils/util.py:550)
+            raise RuntimeError('pyramid level %s cannot be rebuilt from %s' % (tuple(cur.shape), tuple(down.shape)))
+        out = torch.empty_like(cur)
+        _lib.check(_lib.lib().rvsr_pyr_updiff_forward(_p(cur), _p(down), _p(out), B * C, H, W, _stream()),
+                   'pyr_updiff_forward')
+        ctx.cfg = (B, C, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        B, C, H, W = ctx.cfg
+        gout = gout.contiguous()
+        gdown = gout.new_empty(B, C, H // 2, W // 2)
+        _lib.check(_lib.lib().rvsr_pyr_updiff_backward(_p(gout), _p(gdown), B * C, H, W, _stream()),
+                   'pyr_updiff_backward')
+        return gout, gdown
+
+
+def pyr_updiff(cur, down):
+    """cur - upsample(down) (utils/util.py:513-516,548-551)"""
+    return _PyrUpDiff.apply(cur, down)
+
+
+class _Charbonnier(Function):
+    @staticmethod
+    def forward(ctx, x, y, eps, mean):
+        _need_cuda(x, y)
+        x, y = x.contiguous(), y.contiguous()
+        n = x.numel()
+        out = x.new_empty(())
+        L = _lib.lib()
+        ws = _workspace(L.rvsr_charbonnier_workspace_bytes(), x.device)
+        scale = 1.0 / n if mean else 1.0
+        _lib.check(L.rvsr_charbonnier_forward(_p(x), _p(y), n, eps, scale, _p(out), _p(ws), _stream()),
+                   'charbonnier_forward')
+        ctx.cfg = (eps, scale)
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        eps, scale = ctx.cfg
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().rvsr_charbonnier_backward(_p(x), _p(y), _p(g), scale, eps, _p(gx), x.numel(), _stream()),
+                   'charbonnier_backward')
+        gy = -gx if ctx.needs_input_grad[1] else None
+        return gx, gy, None, None
+
+
+def charbonnier(x, y, eps=1e-6, reduction='mean'):
+    return _Charbonnier.apply(x, y, float(eps), reduction == 'mean')

@@ -1,0 +1,128 @@
+"""HIP modulated deformable convolution vs the CPU oracle + committed fixtures.  -m gpu"""
+import pytest
+import torch
+
+from conftest import load_golden, golden_sd
+from gpu_util import check, dev
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+TOL_G = 1e-4  # grad_input is an atomic scatter (order-nondeterministic, like the reference)
+
+
+def _run_hip(x, off, m, w, b, stride, pad, dil, dg, gout):
+    from realvsr_amd.archs.dcn import modulated_deform_conv
+    d = dev()
+    leaves = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, off, m, w, b)]
+    out = modulated_deform_conv(*leaves, stride, pad, dil, 1, dg)
+    out.backward(gout.to(d))
+    torch.cuda.synchronize()
+    return out, [l.grad if l is not None else None for l in leaves]
+
+
+def _run_oracle(x, off, m, w, b, stride, pad, dil, dg, gout):
+    from oracle.dcn_oracle import modulated_deform_conv
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x, off, m, w, b)]
+    out = modulated_deform_conv(*leaves, stride, pad, dil, 1, dg)
+    out.backward(gout)
+    return out, [l.grad if l is not None else None for l in leaves]
+
+
+def _compare(args, gout):
+    out, grads = _run_hip(*args, gout)
+    oref, gref = _run_oracle(*args, gout)
+    check('out', out, oref, TOL)
+    for name, a, r in zip(('grad_input', 'grad_offset', 'grad_mask', 'grad_weight', 'grad_bias'), grads, gref):
+        if r is not None:
+            check(name, a, r, TOL_G)
+
+
+def test_fixture_dcn_op():
+    g = load_golden('dcn_op')
+    t = {k: torch.from_numpy(v) for k, v in g.items() if v.ndim > 0}
+    out, grads = _run_hip(t['x'], t['offset'], t['mask'], t['weight'], t['bias'], 1, 1, 1, int(g['dg']), t['gout'])
+    check('out', out, t['out'], TOL)
+    for name, a in zip(('gx', 'goffset', 'gmask', 'gweight', 'gbias'), grads):
+        check(name, a, t[name], TOL_G)
+
+
+SHAPES = [
+    # B, C, Co, dg, H, W, stride, pad, dil, offset_std, bias
+    (2, 64, 64, 8, 20, 36, 1, 1, 1, 2.0, True),     # EDVR L1-like, cpg 8
+    (1, 128, 128, 8, 12, 40, 1, 1, 1, 1.0, True),   # nf128, cpg 16 (two chunks per group)
+    (2, 16, 12, 4, 7, 9, 1, 1, 1, 3.0, True),       # cpg 4 (two groups per chunk), ragged tile
+    (1, 64, 64, 8, 45, 80, 1, 1, 1, 10.0, True),    # large motion, L3 size of 180x320
+    (1, 32, 40, 4, 9, 33, 1, 1, 1, 1.0, False),     # no bias, Co not multiple of 32
+    (1, 16, 16, 2, 11, 13, 2, 1, 1, 1.0, True),     # stride 2
+    (1, 16, 16, 2, 11, 13, 1, 2, 2, 1.0, True),     # dilation 2
+    (1, 8, 72, 1, 6, 34, 1, 1, 1, 1.0, True),       # Co > 64 (MT=4 path), dg 1
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: '-'.join(str(v) for v in s))
+def test_random_shapes_vs_oracle(shape):
+    B, C, Co, dg, H, W, stride, pad, dil, ostd, with_bias = shape
+    g = torch.Generator().manual_seed(sum(int(v) for v in shape[:9]))
+    Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, dg * 18, Ho, Wo, generator=g) * ostd
+    m = torch.rand(B, dg * 9, Ho, Wo, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g) if with_bias else None
+    gout = torch.randn(B, Co, Ho, Wo, generator=g)
+    _compare((x, off, m, w, b, stride, pad, dil, dg), gout)
+
+
+def test_identities():
+    import torch.nn.functional as F
+    from realvsr_amd.archs.dcn import modulated_deform_conv
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 16, 10, 34, generator=g)
+    w = torch.randn(16, 16, 3, 3, generator=g) / 12
+    b = torch.randn(16, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    out = modulated_deform_conv(x.to(d), torch.zeros(2, 36, 10, 34, device=d), torch.ones(2, 18, 10, 34, device=d),
+                                w.to(d), b.to(d), 1, 1, 1, 1, 2)
+    check('zero offset, unit mask == conv2d', out, ref, TOL)
+    out = modulated_deform_conv(x.to(d), torch.full((2, 36, 10, 34), 100.0, device=d),
+                                torch.ones(2, 18, 10, 34, device=d), w.to(d), b.to(d), 1, 1, 1, 1, 2)
+    check('far offsets == bias', out, b.view(1, -1, 1, 1).expand(2, 16, 10, 34), 0.0)
+
+
+def test_pack_fixture():
+    """ModulatedDeformConvPack (fused conv_offset_mask + DCN) vs the reference wiring fixture."""
+    from realvsr_amd.archs.dcn import ModulatedDeformConvPack
+    g = load_golden('dcn_pack')
+    d = dev()
+    pack = ModulatedDeformConvPack(16, 12, 3, stride=1, padding=1, dilation=1, deformable_groups=4,
+                                   extra_offset_mask=True)
+    pack.load_state_dict(golden_sd(g), strict=True)
+    pack = pack.to(d)
+    x = torch.from_numpy(g['x']).to(d).requires_grad_(True)
+    feat = torch.from_numpy(g['feat']).to(d).requires_grad_(True)
+    out = pack([x, feat])
+    out.backward(torch.from_numpy(g['gout']).to(d))
+    torch.cuda.synchronize()
+    check('out', out, torch.from_numpy(g['out']), TOL)
+    check('gx', x.grad, torch.from_numpy(g['gx']), TOL_G)
+    check('gfeat', feat.grad, torch.from_numpy(g['gfeat']), TOL_G)
+    for k, p in pack.named_parameters():
+        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
+
+
+def test_errors():
+    from realvsr_amd.archs.dcn import modulated_deform_conv, deform_conv
+    with pytest.raises(NotImplementedError):
+        modulated_deform_conv(torch.randn(1, 8, 4, 4), torch.zeros(1, 18, 4, 4), torch.ones(1, 9, 4, 4),
+                              torch.randn(8, 8, 3, 3), None, 1, 1, 1, 1, 1)
+    d = dev()
+    with pytest.raises(RuntimeError):  # 5x5 kernels are not on the HIP path: loud, not silent
+        modulated_deform_conv(torch.randn(1, 8, 8, 8, device=d), torch.zeros(1, 50, 8, 8, device=d),
+                              torch.ones(1, 25, 8, 8, device=d), torch.randn(8, 8, 5, 5, device=d), None, 1, 2, 1, 1, 1)
+    with pytest.raises(RuntimeError):  # non-contiguous input, as deform_conv_cuda.cpp:497
+        modulated_deform_conv(torch.randn(1, 8, 8, 16, device=d)[:, :, :, ::2], torch.zeros(1, 18, 8, 8, device=d),
+                              torch.ones(1, 9, 8, 8, device=d), torch.randn(8, 8, 3, 3, device=d), None, 1, 1, 1, 1, 1)
+    with pytest.raises(ValueError):
+        deform_conv(torch.randn(8, 4, 4), None, None)

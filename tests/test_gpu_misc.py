@@ -1,0 +1,123 @@
+"""Fusion / resampling / pyramid / loss kernels vs torch CPU and the committed fixtures.  -m gpu"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from gpu_util import check, dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize('factor,scale,shape', [(2, 1.0, (2, 5, 7, 9)), (2, 2.0, (1, 16, 12, 20)), (4, 1.0, (2, 3, 8, 12)),
+                                                (2, 1.0, (1, 2, 1, 3))])
+def test_upsample(factor, scale, shape):
+    from realvsr_amd import functional as RF
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(1))
+    gout = torch.randn(shape[0], shape[1], shape[2] * factor, shape[3] * factor, generator=torch.Generator().manual_seed(2))
+    xr = x.double().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=factor, mode='bilinear', align_corners=False) * scale
+    yr.backward(gout.double())
+    xd = x.to(dev()).requires_grad_(True)
+    y = RF.upsample_bilinear(xd, factor, scale)
+    y.backward(gout.to(dev()))
+    check('out', y, yr, TOL)
+    check('grad', xd.grad, xr.grad, TOL)
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 12, 20), (1, 3, 7, 9), (1, 16, 45, 80)])
+def test_maxavgpool(shape):
+    from realvsr_amd import functional as RF
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(3))
+    xr = x.double().requires_grad_(True)
+    yr = torch.cat([F.max_pool2d(xr, 3, 2, 1), F.avg_pool2d(xr, 3, 2, 1)], 1)
+    gout = torch.randn(yr.shape, generator=torch.Generator().manual_seed(4))
+    yr.backward(gout.double())
+    xd = x.to(dev()).requires_grad_(True)
+    y = RF.maxavgpool(xd)
+    y.backward(gout.to(dev()))
+    check('out', y, yr, TOL)
+    check('grad', xd.grad, xr.grad, TOL)
+
+
+def test_tsa_temporal_and_output():
+    from realvsr_amd import functional as RF
+    g = torch.Generator().manual_seed(5)
+    B, N, C, H, W = 2, 5, 16, 9, 13
+    emb, ref, al = torch.randn(B, N, C, H, W, generator=g) * 0.3, torch.randn(B, C, H, W, generator=g) * 0.3, \
+        torch.randn(B, N, C, H, W, generator=g)
+    gout = torch.randn(B, N * C, H, W, generator=g)
+    r = [t.double().requires_grad_(True) for t in (emb, ref, al)]
+    prob = torch.sigmoid((r[0] * r[1].unsqueeze(1)).sum(2, keepdim=True))
+    yr = (r[2] * prob).reshape(B, N * C, H, W)
+    yr.backward(gout.double())
+    t = [v.to(dev()).requires_grad_(True) for v in (emb, ref, al)]
+    y = RF.tsa_temporal(*t)
+    y.backward(gout.to(dev()))
+    check('mod', y, yr, TOL)
+    for name, a, b in zip(('gemb', 'gemb_ref', 'galigned'), t, r):
+        check(name, a.grad, b.grad, TOL)
+
+    fea, att, add = (torch.randn(2, 8, 6, 10, generator=g) for _ in range(3))
+    gout = torch.randn(2, 8, 6, 10, generator=g)
+    r = [v.double().requires_grad_(True) for v in (fea, att, add)]
+    yr = r[0] * torch.sigmoid(r[1]) * 2 + r[2]
+    yr.backward(gout.double())
+    t = [v.to(dev()).requires_grad_(True) for v in (fea, att, add)]
+    y = RF.tsa_output(*t)
+    y.backward(gout.to(dev()))
+    check('tsa_output', y, yr, TOL)
+    for name, a, b in zip(('gfea', 'gatt', 'gadd'), t, r):
+        check(name, a.grad, b.grad, TOL)
+
+
+def test_pyramids_bit_exact_on_integer_images():
+    """Indexing parity: on small-integer images every product/sum is exact in f32, so the result
+    must equal the reference's bit for bit (even-index select, reflect pad, zero insert)."""
+    from realvsr_amd import util
+    g = load_golden('pyramid_int')
+    for tag in 'abc':
+        img = torch.from_numpy(g['img_' + tag]).to(dev())
+        k = util.gauss_kernel(channels=img.shape[1], device=img.device)
+        for name, fn, lv in (('laplacian', util.laplacian_pyramid, 3), ('lap', util.lap_pyramid, 2),
+                             ('gau', util.gau_pyramid, 3)):
+            for i, level in enumerate(fn(img, k, lv)):
+                assert np.array_equal(level.cpu().numpy(), g['%s_%s_%d' % (name, tag, i)]), (name, tag, i)
+
+
+def test_losses_fixture():
+    from realvsr_amd import loss as L
+    g = load_golden('losses')
+    crit = {'lappyr_cb': L.LapPyrLoss(3, 'cb', 'cb', 'mean'), 'lappyr_cb_sum': L.LapPyrLoss(2, 'cb', 'cb', 'sum'),
+            'pyr_gau_cb': L.PyramidLoss(3, 'gau', 'cb', 'mean'), 'pyr_lap_l1': L.PyramidLoss(2, 'lap', 'l1', 'mean'),
+            'pyr_gau_l2': L.PyramidLoss(3, 'gau', 'l2', 'mean'), 'cb': L.CharbonnierLoss()}
+    for tag in ('y', 'rgb'):
+        for name, fn in crit.items():
+            x = torch.from_numpy(g['x_' + tag]).to(dev()).requires_grad_(True)
+            y = torch.from_numpy(g['y_' + tag]).to(dev())
+            l = fn(x, y)
+            l.backward()
+            ref = float(g['%s_%s' % (name, tag)])
+            assert abs(l.item() - ref) <= 2e-6 * abs(ref), (name, tag, l.item(), ref)
+            check('g_%s_%s' % (name, tag), x.grad, torch.from_numpy(g['g_%s_%s' % (name, tag)]), 2e-5)
+
+
+def test_pyramid_full_size_properties():
+    """Size-independent properties at the HR size of BASELINE configs 2-4 (720x1280):
+    linearity of the decomposition and exact reconstruction cur = diff + upsample(down)."""
+    from realvsr_amd import util, functional as RF
+    d = dev()
+    g = torch.Generator(device='cpu').manual_seed(7)
+    a = torch.rand(2, 1, 720, 1280, generator=g).to(d)
+    b = torch.rand(2, 1, 720, 1280, generator=g).to(d)
+    pa, pb, pab = util.laplacian_pyramid(a, None, 3), util.laplacian_pyramid(b, None, 3), util.laplacian_pyramid(a + b, None, 3)
+    for i in range(3):
+        check('linearity level %d' % i, pab[i], pa[i] + pb[i], 1e-5)
+    # collapse: level0 + up(level1 + up(level2)) == image, with up(x) = x_zero - pyr_updiff(x_zero, x)
+    z1 = torch.zeros_like(pa[1])
+    rec1 = pa[1] + (z1 - RF.pyr_updiff(z1, pa[2]))
+    z0 = torch.zeros_like(pa[0])
+    rec0 = pa[0] + (z0 - RF.pyr_updiff(z0, rec1))
+    check('collapse reconstructs the image', rec0, a, 1e-5)

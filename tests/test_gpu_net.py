@@ -1,0 +1,111 @@
+"""PCD_Align / TSA_Fusion / EDVR on the HIP path vs reference-import fixtures and the oracle.  -m gpu"""
+import pytest
+import torch
+
+from conftest import load_golden, golden_sd
+from gpu_util import check, dev
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-5
+TOL_G = 3e-4
+
+
+def _t(g, k, grad=False):
+    return torch.from_numpy(g[k]).to(dev()).requires_grad_(grad)
+
+
+def test_pcd_align_fixture():
+    from realvsr_amd.archs.EDVR_arch import PCD_Align
+    g = load_golden('pcd_align')
+    pcd = PCD_Align(nf=int(g['nf']), groups=int(g['groups']))
+    pcd.load_state_dict(golden_sd(g), strict=True)
+    pcd = pcd.to(dev())
+    nbr = [_t(g, 'nbr%d' % l, True) for l in range(3)]
+    ref = [_t(g, 'ref%d' % l, True) for l in range(3)]
+    out = pcd(nbr, ref)
+    out.backward(_t(g, 'gout'))
+    check('out', out, torch.from_numpy(g['out']), TOL)
+    for l in range(3):
+        check('gnbr%d' % l, nbr[l].grad, torch.from_numpy(g['gnbr%d' % l]), TOL_G)
+        check('gref%d' % l, ref[l].grad, torch.from_numpy(g['gref%d' % l]), TOL_G)
+    for k, p in pcd.named_parameters():
+        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
+
+
+def test_tsa_fusion_fixture():
+    from realvsr_amd.archs.EDVR_arch import TSA_Fusion
+    g = load_golden('tsa_fusion')
+    tsa = TSA_Fusion(nf=16, nframes=3, center=1)
+    tsa.load_state_dict(golden_sd(g), strict=True)
+    tsa = tsa.to(dev())
+    al = _t(g, 'aligned', True)
+    out = tsa(al)
+    out.backward(_t(g, 'gout'))
+    check('out', out, torch.from_numpy(g['out']), TOL)
+    check('galigned', al.grad, torch.from_numpy(g['galigned']), TOL_G)
+    for k, p in tsa.named_parameters():
+        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
+
+
+def _loss(out, gt):
+    from realvsr_amd import loss as L
+    return L.LapPyrLoss(3, 'cb', 'cb', 'mean')(out[:, 0:1], gt[:, 0:1]) + L.CharbonnierLoss()(out[:, 1:3], gt[:, 1:3])
+
+
+def test_edvr_tsa_fixture():
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    g = load_golden('edvr_tsa')
+    net = EDVR(nf=16, nc=3, nframes=3, groups=4, front_RBs=2, back_RBs=2, w_TSA=True)
+    net.load_state_dict(golden_sd(g), strict=True)
+    net = net.to(dev())
+    out = net(_t(g, 'x'))
+    check('out', out, torch.from_numpy(g['out']), TOL)
+    loss = _loss(out, _t(g, 'gt'))
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss'])), (loss.item(), float(g['loss']))
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item()
+    assert abs(gnorm - float(g['gnorm'])) <= 1e-3 * float(g['gnorm']), (gnorm, float(g['gnorm']))
+    for k, p in net.named_parameters():
+        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), 1e-3)
+
+
+def test_edvr_noup_fixture():
+    from weights import fill_state_dict
+    from realvsr_amd.archs.EDVR_arch import EDVR_NoUp
+    g = load_golden('edvr_noup')
+    net = EDVR_NoUp(nf=64, nc=3, nframes=3, groups=8, front_RBs=1, back_RBs=1, w_TSA=False)
+    fill_state_dict(net, 77)
+    net = net.to(dev())
+    out = net(_t(g, 'x'))
+    check('out', out, torch.from_numpy(g['out']), TOL)
+    loss = _loss(out, _t(g, 'gt'))
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    grads = dict(net.named_parameters())
+    for k in [k for k in g if k.startswith('grad.')]:
+        check(k, grads[k[5:]].grad, torch.from_numpy(g[k]), 1e-3)
+
+
+def test_config1_vs_oracle_psnr():
+    """BASELINE config 1: one 5-frame 64x64 LR window, EDVR-M nf64 / 5 front / 10 back RBs / TSA, forward.
+    HIP output vs the CPU oracle on identical weights and input; PSNR-Y as train.py:301-305."""
+    from oracle import edvr_oracle as O
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    torch.manual_seed(0)
+    net = EDVR(nf=64, nc=3, nframes=5, groups=8, front_RBs=5, back_RBs=10, w_TSA=True)
+    gen = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if 'conv_offset_mask.weight' in name:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.01)
+    x = torch.rand(1, 5, 3, 64, 64, generator=torch.Generator().manual_seed(1234))
+    gt = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(1235))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = O.edvr_forward(sd, x, nframes=5, groups=8, front_RBs=5, back_RBs=10, w_TSA=True)
+        out = net.to(dev())(x.to(dev())).cpu()
+    check('config-1 output', out, ref, TOL)
+    p_build, p_oracle = O.psnr_y_uint8(out, gt), O.psnr_y_uint8(ref, gt)
+    print('PSNR-Y vs synthetic GT: build %.6f dB, oracle %.6f dB; build-vs-oracle %.2f dB'
+          % (p_build, p_oracle, O.psnr_y_uint8(out, ref)))
+    assert abs(p_build - p_oracle) <= 1e-3
