@@ -1,0 +1,71 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol the header
+declares, the Python mirror keeps the reference's API / state_dict schema, and nothing silently
+falls back to the CPU."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO, load_golden, golden_sd
+
+
+def _header_symbols():
+    text = open(os.path.join(REPO, 'include', 'realvsr_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(rvsr_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from realvsr_amd import _lib
+    _lib.build()
+    L = _lib.lib()
+    declared = _header_symbols()
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(L, name), name
+        assert name in _lib.SIGNATURES, 'ctypes signature missing for ' + name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_operators_refuse_cpu_tensors():
+    from realvsr_amd.archs.dcn import modulated_deform_conv, ModulatedDeformConvPack
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    from realvsr_amd import loss as L
+    with pytest.raises(NotImplementedError):
+        modulated_deform_conv(torch.randn(1, 8, 4, 4), torch.zeros(1, 18, 4, 4), torch.ones(1, 9, 4, 4),
+                              torch.randn(8, 8, 3, 3), None, 1, 1, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        ModulatedDeformConvPack(8, 8, 3, padding=1, deformable_groups=1)(torch.randn(1, 8, 4, 4))
+    with pytest.raises(NotImplementedError):
+        EDVR(nf=16, nframes=3, groups=4, front_RBs=1, back_RBs=1)(torch.rand(1, 3, 3, 8, 8))
+    with pytest.raises(NotImplementedError):
+        L.LapPyrLoss(3, 'cb', 'cb')(torch.rand(1, 1, 16, 16), torch.rand(1, 1, 16, 16))
+    with pytest.raises(NotImplementedError):
+        L.LapPyrLoss(3, 'ssim', 'cb')  # IQA_pytorch is not vendored by the reference: parity unpinned
+
+
+def test_state_dict_schema_matches_reference():
+    """Keys/shapes of the fixtures come from instantiating the reference modules (make_golden.py)."""
+    from realvsr_amd.archs.EDVR_arch import EDVR, PCD_Align, TSA_Fusion
+    from realvsr_amd.archs.dcn import ModulatedDeformConvPack
+    for name, mod in [('edvr_tsa', EDVR(nf=16, nc=3, nframes=3, groups=4, front_RBs=2, back_RBs=2, w_TSA=True)),
+                      ('pcd_align', PCD_Align(nf=16, groups=4)), ('tsa_fusion', TSA_Fusion(nf=16, nframes=3, center=1)),
+                      ('dcn_pack', ModulatedDeformConvPack(16, 12, 3, stride=1, padding=1, dilation=1,
+                                                           deformable_groups=4, extra_offset_mask=True))]:
+        mod.load_state_dict(golden_sd(load_golden(name)), strict=True)
+    net = EDVR(nf=64, nc=3, nframes=5, groups=8, front_RBs=5, back_RBs=10, w_TSA=True)
+    assert len(net.state_dict()) == 144 and sum(p.numel() for p in net.parameters()) == 3300131
+    pack = ModulatedDeformConvPack(16, 12, 3, padding=1, deformable_groups=4)
+    assert float(pack.conv_offset_mask.weight.abs().sum()) == 0.0 and float(pack.bias.abs().sum()) == 0.0
+
+
+def test_define_g():
+    from realvsr_amd.VideoSR_archs import define_G
+    from realvsr_amd.archs.EDVR_arch import EDVR_NoUp
+    opt = {'network_G': {'which_model_G': 'EDVR_NoUp', 'nf': 64, 'nc': 3, 'nframes': 3, 'groups': 8, 'front_RBs': 5,
+                         'back_RBs': 10, 'w_TSA': False}}
+    net = define_G(opt)
+    assert isinstance(net, EDVR_NoUp) and net.center == 1 and isinstance(net.tsa_fusion, torch.nn.Conv2d)
+    with pytest.raises(NotImplementedError):
+        define_G({'network_G': {'which_model_G': 'TDAN'}})
