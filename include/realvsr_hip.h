@@ -33,6 +33,12 @@ extern "C" {
 
 const char* rvsr_last_error(void);
 
+/* GEMM arithmetic of the conv blocks: 0 (default) = 3-term bf16 split on the bf16 matrix cores
+ * (a = a_hi + a_lo; a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in f32; ~2^-17 relative error
+ * per product), 1 = exact f32 MFMA (an fmaf chain; ~5x slower GEMMs).  Process-wide switch. */
+void rvsr_set_gemm_mode(int mode);
+int rvsr_get_gemm_mode(void);
+
 /* ---------------------------------------------------------------------------------------------
  * 1. Modulated deformable convolution (DCNv2)
  * --------------------------------------------------------------------------------------------- */
@@ -106,12 +112,15 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
  *   residual (NULL or shaped like out1, out2 must be NULL): added after the activation.
  *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
  *   pixel_shuffle 1: out1 is (B,Co/4,2*Hout,2*Wout), written through PixelShuffle(2).
- *   stride 2 only with ksize 3 and in_mode 0. */
+ *   stride 2 only with ksize 3 and in_mode 0.
+ *   workspace: rvsr_conv2d_forward_workspace_bytes(C1, C2, Co1+Co2, ksize) bytes (holds the weights
+ *   re-packed as bf16 hi/lo for the matrix cores; unused in exact-f32 mode). */
+size_t rvsr_conv2d_forward_workspace_bytes(int C1, int C2, int Co, int ksize);
 int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const float* xact, float xact_slope,
                         int in_mode, int Hs, int Ws, const float* weight, const float* bias,
                         const float* residual, float* out1, int Co1, float* out2, int Co2, int B, int ksize,
                         int stride, int w_mode, int act, float slope, int pixel_shuffle, int Hout, int Wout,
-                        void* stream);
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* grad_weight (Co,C1+C2,k,k) and grad_bias (Co) (NULL = skip) of the conv above.
  *   gout: gradient w.r.t. the conv output.  g_mode 0: stored (B,Co,Gs_h,Gs_w) = (.., Hout, Wout);

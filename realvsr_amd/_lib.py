@@ -24,7 +24,10 @@ SIGNATURES = {
     'rvsr_dcn_pack_backward': (c_int, [c_fp] * 5 + [c_float] + [c_fp] * 4 + [c_int] * 9 + [c_fp, c_size, c_fp]),
     'rvsr_conv2d_forward': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_float, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                     c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
-                                    c_int, c_int, c_fp]),
+                                    c_int, c_int, c_fp, c_size, c_fp]),
+    'rvsr_conv2d_forward_workspace_bytes': (c_size, [c_int] * 4),
+    'rvsr_set_gemm_mode': (None, [c_int]),
+    'rvsr_get_gemm_mode': (c_int, []),
     'rvsr_conv2d_wgrad_workspace_bytes': (c_size, [c_int] * 8),
     'rvsr_conv2d_backward_weight': (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_float, c_int, c_int,
                                             c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
@@ -70,8 +73,22 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args
+        mode = os.environ.get('RVSR_GEMM', 'bf16x3')
+        if mode not in ('bf16x3', 'f32'):
+            raise RuntimeError("RVSR_GEMM must be 'bf16x3' or 'f32', got %r" % mode)
+        handle.rvsr_set_gemm_mode(1 if mode == 'f32' else 0)
         _lib = handle
     return _lib
+
+
+def set_gemm_mode(mode):
+    """'bf16x3' (default: 3-term bf16 split on the bf16 matrix cores, ~2^-17 relative error per
+    product) or 'f32' (exact-f32 MFMA, bit-for-bit an fmaf chain, ~5x slower GEMMs)."""
+    lib().rvsr_set_gemm_mode({'bf16x3': 0, 'f32': 1}[mode])
+
+
+def get_gemm_mode():
+    return 'f32' if lib().rvsr_get_gemm_mode() else 'bf16x3'
 
 
 def check(rc, what):

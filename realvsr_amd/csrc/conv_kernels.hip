@@ -19,70 +19,7 @@
 // buffer exists anywhere.
 #include "rvsr_common.h"
 
-struct ConvFwdParams {
-    TCat in;
-    const float* w;
-    const float* bias;
-    const float* res;
-    float* out1;
-    float* out2;
-    int Co1;
-    int B, Co, Hout, Wout;
-    int w_mode;
-    int act;
-    float slope;
-    int ps;
-    int ntx;
-};
-
-
-// MODE 0: plain store, 1: + residual, 2: channel split into out1/out2, 3: pixel-shuffle(2) store.
-// Branch-free per element except the final predicated store (the fully unrolled 16*MT*2 stores
-// otherwise explode into thousands of basic blocks and spill the accumulators).
-template <int MT, int MODE>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][2], const ConvFwdParams& p, int b, int o0, int row0,
-                                              int col, int hi) {
-    const bool has_bias = p.bias != nullptr;
-    const float* bp = has_bias ? p.bias : p.w;  // p.w: any valid address, value discarded
-    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
-    const bool col_ok = col < p.Wout;
-    const size_t HW = (size_t)p.Hout * p.Wout;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int row = row0 + n;
-        if (row >= p.Hout) continue;  // wave-uniform
-        const size_t pix = (size_t)row * p.Wout + col;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = o0 + m * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
-                const bool ok = col_ok && o < p.Co;
-                const int oc = ok ? o : 0;
-                float v = acc[m][n][r];
-                const float bb = bp[oc];
-                v += has_bias ? bb : 0.f;
-                v = v > 0.f ? v : v * neg;
-                if (MODE == 3) {
-                    const size_t idx = (((size_t)b * (p.Co >> 2) + (oc >> 2)) * (2 * p.Hout) + 2 * row + ((oc >> 1) & 1)) *
-                                           (2 * p.Wout) + 2 * col + (oc & 1);
-                    if (ok) p.out1[idx] = v;
-                } else if (MODE == 2) {
-                    const bool first = oc < p.Co1;
-                    float* dst = first ? p.out1 : p.out2;
-                    const size_t idx = ((size_t)b * (first ? p.Co1 : p.Co - p.Co1) + (first ? oc : oc - p.Co1)) * HW + pix;
-                    if (ok) dst[idx] = v;
-                } else {
-                    const size_t idx = ((size_t)b * p.Co + oc) * HW + pix;
-                    if (ok) {
-                        if (MODE == 1) v += p.res[idx];
-                        p.out1[idx] = v;
-                    }
-                }
-            }
-        }
-    }
-}
+#include "conv_common.h"
 
 template <int KS, int STRIDE, int MT, int CC>
 __global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd_kernel(const ConvFwdParams p) {
@@ -173,14 +110,6 @@ __global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd_kernel(const ConvFwdParam
 }
 
 // ------------------------------------------------------------------------------------------
-struct ConvWgradParams {
-    TCat x;      // the conv's (virtual) input
-    TView g;     // gradient w.r.t. the conv output: virtual (Co, Hout, Wout); g.act fuses act'
-    float* part;   // [P][Co][Ctot][T]
-    float* bpart;  // [P][Co] or nullptr
-    int B, Co, Hout, Wout, ntx, nty, P;
-};
-
 template <int KS, int STRIDE, int CCW>
 __global__ __launch_bounds__(RVSR_WG) void conv_wgrad_kernel(const ConvWgradParams p) {
     constexpr int T = KS * KS, PAD = KS / 2, TH = 4, TW = 32, NPX = TH * TW;
@@ -281,16 +210,6 @@ __global__ __launch_bounds__(RVSR_WG) void conv_wgrad_kernel(const ConvWgradPara
     }
 }
 
-// dst[i] (+)= sum_p part[p][i]   (fixed summation order -> run-to-run deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst,
-                                       int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int q = 0; q < P; ++q) s += part[(size_t)q * n + i];
-        dst[i] = accumulate ? dst[i] + s : s;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 
@@ -339,7 +258,8 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
                                    float xact_slope, int in_mode, int Hs, int Ws, const float* weight,
                                    const float* bias, const float* residual, float* out1, int Co1, float* out2,
                                    int Co2, int B, int ksize, int stride, int w_mode, int act, float slope,
-                                   int pixel_shuffle, int Hout, int Wout, void* stream) {
+                                   int pixel_shuffle, int Hout, int Wout, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
     if (!x1 || !weight || !out1 || B <= 0 || C1 <= 0 || Co1 <= 0) FAIL(RVSR_ERR_BAD_ARG, "conv2d: null/empty argument");
     if ((x2 == nullptr) != (C2 == 0) || (out2 == nullptr) != (Co2 == 0))
         FAIL(RVSR_ERR_BAD_ARG, "conv2d: second input/output pointer and channel count disagree");
@@ -373,6 +293,9 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
     p.ps = pixel_shuffle;
     p.ntx = (Wout + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    p.wpack = nullptr;
+    if (rvsr_g_gemm_mode == 0 && (in_mode == 0 || in_mode == 2) && (x2 == nullptr || C1 % 8 == 0))
+        return rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
     const int mt = p.Co <= 32 ? 1 : (p.Co <= 64 ? 2 : 4);
 #define DISPATCH(KS, S, CC12, CC4)                                \
     do {                                                           \
@@ -386,8 +309,15 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
 #undef DISPATCH
 }
 
+int rvsr_g_gemm_mode = 0;
+extern "C" void rvsr_set_gemm_mode(int mode) { rvsr_g_gemm_mode = mode ? 1 : 0; }
+extern "C" int rvsr_get_gemm_mode() { return rvsr_g_gemm_mode; }
+extern "C" size_t rvsr_conv2d_forward_workspace_bytes(int C1, int C2, int Co, int ksize) {
+    return rvsr_conv_fwd2_workspace_bytes(ksize, Co, C1 + C2);
+}
+
 static int wgrad_P(int ntiles, int gy, int gz) {
-    int P = 512 / (gy * gz);
+    int P = 256 / (gy * gz);
     if (P < 1) P = 1;
     if (P > ntiles) P = ntiles;
     return P;
@@ -463,10 +393,8 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     else
         rc = launch_wgrad<1, 1, 64>(p, gy, gz, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256)), dim3(256), 0,
-                       st, p.part, p.P, nw, grad_weight, accumulate);
-    if (grad_bias)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.bpart, p.P, (size_t)Co, grad_bias, accumulate);
+    rvsr_launch_reduce(p.part, p.P, nw, grad_weight, accumulate, st);
+    if (grad_bias) rvsr_launch_reduce(p.bpart, p.P, (size_t)Co, grad_bias, accumulate, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad reduce launch: %s", hipGetErrorString(e));
     return RVSR_OK;

@@ -89,10 +89,11 @@ __device__ __forceinline__ Samp dcn_sample(const DcnGeom& d, int b, int g, int k
 // Build the column tile of channel chunk [c0, c0+8) for the 128 pixels of a tile.
 // COLT == false: col[k * 128 + px]      (k-major; B operand of the forward GEMM)
 // COLT == true : col[px * ldc + k]       (pixel-major; B operand of the weight-gradient GEMM)
-template <bool COLT>
+template <bool COLT, int CHS>
 __device__ __forceinline__ void dcn_build_cols(const DcnGeom& d, int b, int c0, int y0, int x0, float* col, int ldc,
                                                int tid) {
-    const int chs = d.cpg < DCN_CC ? d.cpg : DCN_CC;  // channels sharing one offset set inside the chunk
+    // channels sharing one offset set inside the chunk (CHS > 0: compile-time -> unrolled gathers)
+    const int chs = CHS > 0 ? CHS : (d.cpg < DCN_CC ? d.cpg : DCN_CC);
     const int nslots = DCN_CC / chs;
     const int nitems = DCN_NPX * 9 * nslots;
     const size_t HW = (size_t)d.H * d.W;
@@ -105,10 +106,12 @@ __device__ __forceinline__ void dcn_build_cols(const DcnGeom& d, int b, int c0, 
         const bool live = oy < d.Ho && ox < d.Wo && cb < d.C;
         Samp s;
         if (live) s = dcn_sample(d, b, cb / d.cpg, k, oy, ox);
-        for (int j = 0; j < chs; ++j) {
+        const bool go = live && s.inside;
+#pragma unroll
+        for (int j = 0; j < (CHS > 0 ? CHS : chs); ++j) {
             const int c = cb + j;
             float v = 0.f;
-            if (live && c < d.C && s.inside) {
+            if (go && c < d.C) {
                 const float* pl = d.x + ((size_t)b * d.C + c) * HW;
                 v = (s.w00 * pl[s.i00] + s.w01 * pl[s.i01] + s.w10 * pl[s.i10] + s.w11 * pl[s.i11]) * s.m;
             }
@@ -131,7 +134,7 @@ struct DcnFwdParams {
     float slope;
 };
 
-template <int MT>
+template <int MT, int CHS>
 __global__ __launch_bounds__(RVSR_WG, 2) void dcn_fwd_kernel(const DcnFwdParams p) {
     constexpr int MP = MT * 32, MPP = MP + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(RVSR_WG, 2) void dcn_fwd_kernel(const DcnFwdParams 
             if (o < d.Co && kg < K) v = p.w[(size_t)o * K + kg];
             ws[kk * MPP + m] = v;
         }
-        dcn_build_cols<false>(d, b, c0, y0, x0, col, 0, tid);
+        dcn_build_cols<false, CHS>(d, b, c0, y0, x0, col, 0, tid);
         __syncthreads();
 #pragma unroll 4
         for (int ks = 0; ks < DCN_KC / 2; ++ks) {
@@ -203,6 +206,7 @@ struct DcnBwdInParams {
     size_t goff_bs, gmask_bs;
 };
 
+template <int CHS>
 __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdInParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DcnGeom& d = p.d;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdI
         gs[e] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
     }
 
-    const int chs = d.cpg < DCN_CC ? d.cpg : DCN_CC;
+    const int chs = CHS > 0 ? CHS : (d.cpg < DCN_CC ? d.cpg : DCN_CC);
     const int nslots = DCN_CC / chs;
     const int nitems = DCN_NPX * 9 * nslots;
 
@@ -269,9 +273,10 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdI
             float gy = 0.f, gxo = 0.f, gm = 0.f;
             if (s.inside) {
                 const float hy = 1.f - s.ly, hx = 1.f - s.lx;
-                for (int j = 0; j < chs; ++j) {
+#pragma unroll
+                for (int j = 0; j < (CHS > 0 ? CHS : chs); ++j) {
                     const int c = cb + j;
-                    if (c >= d.C) break;
+                    if (c >= d.C) continue;
                     const float cgv = cg[((slot * chs + j) * 9 + k) * DCN_NPX + px];
                     const float* pl = d.x + ((size_t)b * d.C + c) * HW;
                     const float l00 = pl[s.i00], l01 = pl[s.i01], l10 = pl[s.i10], l11 = pl[s.i11];
@@ -318,6 +323,7 @@ struct DcnBwdWParams {
     int P, nty;
 };
 
+template <int CHS>
 __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_weight_kernel(const DcnBwdWParams p) {
     constexpr int GP = 65, CP = 97;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_weight_kernel(const DcnBwd
             const int o = mb * 64 + ol;
             gT[px * GP + ol] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
         }
-        dcn_build_cols<true>(d, b, c0, y0, x0, colT, CP, tid);
+        dcn_build_cols<true, CHS>(d, b, c0, y0, x0, colT, CP, tid);
         __syncthreads();
 #pragma unroll 2
         for (int ks = 0; ks < 16; ++ks) {
@@ -385,14 +391,6 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_weight_kernel(const DcnBwd
     }
 }
 
-__global__ void dcn_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int q = 0; q < P; ++q) s += part[(size_t)q * n + i];
-        dst[i] += s;  // the reference accumulates into caller-zeroed gW/gBias (cpp:659-671)
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 
@@ -421,17 +419,26 @@ static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, 
     DcnFwdParams p;
     p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act; p.slope = slope;
     const int nty = (d.Ho + 3) / 4;
-    if (d.Co <= 32) {
-        const size_t lds = sizeof(float) * (DCN_KC * DCN_NPX + DCN_KC * 33);
-        hipLaunchKernelGGL(dcn_fwd_kernel<1>, dim3(d.ntx * nty, (d.Co + 31) / 32, d.B), dim3(RVSR_WG), lds, st, p);
-    } else if (d.Co <= 64) {
-        const size_t lds = sizeof(float) * (DCN_KC * DCN_NPX + DCN_KC * 65);
-        hipLaunchKernelGGL(dcn_fwd_kernel<2>, dim3(d.ntx * nty, (d.Co + 63) / 64, d.B), dim3(RVSR_WG), lds, st, p);
-    } else {
-        const size_t lds = sizeof(float) * (DCN_KC * DCN_NPX + DCN_KC * 129);
-        if (set_lds(dcn_fwd_kernel<4>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd: cannot reserve %zu B of LDS", lds);
-        hipLaunchKernelGGL(dcn_fwd_kernel<4>, dim3(d.ntx * nty, (d.Co + 127) / 128, d.B), dim3(RVSR_WG), lds, st, p);
-    }
+    const bool c8 = d.cpg % DCN_CC == 0;  // every chunk of 8 channels shares one offset set
+#define LAUNCH_FWD(MT)                                                                                              \
+    do {                                                                                                            \
+        const size_t lds = sizeof(float) * (DCN_KC * DCN_NPX + DCN_KC * (MT * 32 + 1));                             \
+        const dim3 grid(d.ntx * nty, (d.Co + MT * 32 - 1) / (MT * 32), d.B);                                        \
+        if (c8) {                                                                                                   \
+            if (set_lds(dcn_fwd_kernel<MT, 8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd: cannot reserve %zu B of LDS", lds); \
+            hipLaunchKernelGGL((dcn_fwd_kernel<MT, 8>), grid, dim3(RVSR_WG), lds, st, p);                           \
+        } else {                                                                                                    \
+            if (set_lds(dcn_fwd_kernel<MT, 0>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd: cannot reserve %zu B of LDS", lds); \
+            hipLaunchKernelGGL((dcn_fwd_kernel<MT, 0>), grid, dim3(RVSR_WG), lds, st, p);                           \
+        }                                                                                                           \
+    } while (0)
+    if (d.Co <= 32)
+        LAUNCH_FWD(1);
+    else if (d.Co <= 64)
+        LAUNCH_FWD(2);
+    else
+        LAUNCH_FWD(4);
+#undef LAUNCH_FWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd launch: %s", hipGetErrorString(e));
     return RVSR_OK;
@@ -468,8 +475,13 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         const int CoP = (d.Co + 1) & ~1;
         const size_t lds = sizeof(float) * ((size_t)CoP * DCN_NPX + (size_t)CoP * DCN_KC + DCN_KC * DCN_NPX);
         if (lds > 160 * 1024) FAIL(RVSR_ERR_UNSUPPORTED, "dcn backward: channels_out %d needs %zu B of LDS", d.Co, lds);
-        if (set_lds(dcn_bwd_input_kernel, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
-        hipLaunchKernelGGL(dcn_bwd_input_kernel, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);
+        if (d.cpg % DCN_CC == 0) {
+            if (set_lds(dcn_bwd_input_kernel<8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(dcn_bwd_input_kernel<8>, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);
+        } else {
+            if (set_lds(dcn_bwd_input_kernel<0>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(dcn_bwd_input_kernel<0>, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);
+        }
     }
     if (gw) {
         DcnBwdWParams p;
@@ -480,11 +492,16 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         p.part = (float*)workspace;
         p.bpart = gb ? p.part + Q * nw : nullptr;
         const size_t lds = sizeof(float) * (DCN_NPX * 65 + DCN_NPX * 97);
-        if (set_lds(dcn_bwd_weight_kernel, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_weight: cannot reserve %zu B of LDS", lds);
-        hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
-        const unsigned nb = (unsigned)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256);
-        hipLaunchKernelGGL(dcn_reduce_partials_kernel, dim3(nb), dim3(256), 0, st, p.part, (int)Q, nw, gw);
-        if (gb) hipLaunchKernelGGL(dcn_reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.bpart, (int)Q, (size_t)d.Co, gb);
+        if (d.cpg % DCN_CC == 0) {
+            if (set_lds(dcn_bwd_weight_kernel<8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_weight: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(dcn_bwd_weight_kernel<8>, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
+        } else {
+            if (set_lds(dcn_bwd_weight_kernel<0>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_weight: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(dcn_bwd_weight_kernel<0>, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
+        }
+        // the reference accumulates into caller-zeroed gW/gBias (cpp:659-671) -> accumulate = 1
+        rvsr_launch_reduce(p.part, (int)Q, nw, gw, 1, st);
+        if (gb) rvsr_launch_reduce(p.bpart, (int)Q, (size_t)d.Co, gb, 1, st);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward launch: %s", hipGetErrorString(e));

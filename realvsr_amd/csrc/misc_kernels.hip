@@ -9,6 +9,7 @@
 // All kernels: one thread per output element, lanes along W (coalesced), grid-stride loops.
 // Backward kernels are gathers that re-evaluate the forward index map over a conservative
 // candidate window (no atomics -> deterministic).
+#define RVSR_DEFINE_REDUCE
 #include "rvsr_common.h"
 
 #define GRID_FOR(n) dim3((unsigned)(((n) + 255) / 256 > 4096 ? 4096 : ((n) + 255) / 256))

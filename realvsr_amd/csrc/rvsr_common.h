@@ -90,6 +90,35 @@ __device__ __forceinline__ float tcat_get(const TCat& t, int bidx, int c, int y,
 #define RVSR_ERR_LAUNCH 3
 #define RVSR_ERR_WORKSPACE 4
 
+// dst[i] (+)= sum_q part[q][i], q < P: 64 elements per block, 4 thread groups stride over the
+// partials (fixed order -> run-to-run deterministic), combined through LDS.
+__global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst, int accumulate);
+#ifdef RVSR_DEFINE_REDUCE
+__global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst, int accumulate) {
+    __shared__ float red[4][64];
+    const int ex = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + ex;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int q = grp;
+        for (; q + 4 < P; q += 8) {
+            s0 += part[(size_t)q * n + i];
+            s1 += part[(size_t)(q + 4) * n + i];
+        }
+        if (q < P) s0 += part[(size_t)q * n + i];
+    }
+    red[grp][ex] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float s = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
+        dst[i] = accumulate ? dst[i] + s : s;
+    }
+}
+#endif
+static inline void rvsr_launch_reduce(const float* part, int P, size_t n, float* dst, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(rvsr_reduce_partials_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, P, n, dst, accumulate);
+}
+
 #include <stdio.h>
 // one error string per host thread, shared by all translation units (defined in misc_kernels.hip)
 extern thread_local char rvsr_g_err[256];

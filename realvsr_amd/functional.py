@@ -71,9 +71,10 @@ class _Conv2dFused(Function):
         else:
             out = x1.new_empty(B, Co, Ho, Wo)
         L = _lib.lib()
+        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C1, C2, Co, k), x1.device)
         _lib.check(L.rvsr_conv2d_forward(_p(x1), C1, _p(x2), C2, None, 0.0, 0, H, W, _p(weight), _p(bias),
                                          _p(residual), _p(out), Co, None, 0, B, k, stride, 0, act, slope,
-                                         int(pixel_shuffle), Ho, Wo, _stream()), 'conv2d_forward')
+                                         int(pixel_shuffle), Ho, Wo, _p(ws), ws.numel(), _stream()), 'conv2d_forward')
         ctx.cfg = (stride, act, slope, bool(pixel_shuffle), C1, C2, H, W, Ho, Wo, k, bias is not None,
                    residual is not None)
         ctx.save_for_backward(x1, x2, weight, out if act != ACT_NONE else None)
@@ -94,9 +95,11 @@ class _Conv2dFused(Function):
             gx1 = torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
             in_mode = 2 if ps else (1 if stride == 2 else 0)
+            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1 + C2, k), x1.device)
             _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2],
                                              gout.shape[3], _p(weight), None, None, _p(gx1), C1, _p(gx2), C2, B, k,
-                                             1, 1, ACT_NONE, 0.0, 0, H, W, _stream()), 'conv2d_backward_data')
+                                             1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                       'conv2d_backward_data')
         if need_w or (has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(weight)
             gb = weight.new_empty(Co) if has_bias else None
