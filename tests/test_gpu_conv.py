@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from gpu_util import check, dev
+from gpu_util import check, dev, gemm_modes
 
 pytestmark = pytest.mark.gpu
 # exact-f32 MFMA: an fmaf chain -> tight; bf16x3 split: ~2^-17 per product
@@ -46,13 +46,7 @@ def _ref(x1, x2, w, b, res, stride, act, ps):
     return y
 
 
-@pytest.fixture(params=['bf16x3', 'f32'])
-def gemm_mode(request):
-    from realvsr_amd import _lib
-    old = _lib.get_gemm_mode()
-    _lib.set_gemm_mode(request.param)
-    yield request.param
-    _lib.set_gemm_mode(old)
+gemm_mode = gemm_modes()
 
 
 @pytest.mark.parametrize('case', CASES, ids=lambda c: '-'.join(str(v) for v in c))
@@ -71,6 +65,13 @@ def test_conv_block_forward_backward(case, gemm_mode):
     oshape = (B, Co // 4, 2 * Ho, 2 * Wo) if ps else (B, Co, Ho, Wo)
     res = torch.randn(oshape, generator=g) if use_res else None
     gout = torch.randn(oshape, generator=g)
+    if act != 'none':
+        # keep the comparison away from the activation kink: where the exact pre-activation is within
+        # 1e-3 of zero the derivative legitimately depends on the last bits of the GEMM
+        with torch.no_grad():
+            z = _ref(x1.double(), None if x2 is None else x2.double(), conv.weight.double(), conv.bias.double(), None,
+                     stride, 'none', ps)
+            gout = gout * (z.abs() > 1e-3).float()
 
     # float64 CPU reference
     r = [t.double().requires_grad_(True) if t is not None else None for t in (x1, x2, res)]

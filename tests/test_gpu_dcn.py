@@ -3,7 +3,9 @@ import pytest
 import torch
 
 from conftest import load_golden, golden_sd
-from gpu_util import check, dev
+from gpu_util import check, check_l2, dev, gemm_modes
+
+gemm_mode = gemm_modes()
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -91,9 +93,11 @@ def test_identities():
     check('far offsets == bias', out, b.view(1, -1, 1, 1).expand(2, 16, 10, 34), 0.0)
 
 
-def test_pack_fixture():
-    """ModulatedDeformConvPack (fused conv_offset_mask + DCN) vs the reference wiring fixture."""
+def test_pack_fixture(gemm_mode):
+    """ModulatedDeformConvPack (fused conv_offset_mask + DCN) vs the reference wiring fixture.
+    The offsets come out of a conv block, so in bf16x3 mode they carry ~1e-5 px of noise."""
     from realvsr_amd.archs.dcn import ModulatedDeformConvPack
+    TOL, TOL_G = (2e-5, 1e-4) if gemm_mode == 'f32' else (5e-4, 2e-3)
     g = load_golden('dcn_pack')
     d = dev()
     pack = ModulatedDeformConvPack(16, 12, 3, stride=1, padding=1, dilation=1, deformable_groups=4,

@@ -3,18 +3,26 @@ import pytest
 import torch
 
 from conftest import load_golden, golden_sd
-from gpu_util import check, dev
+from gpu_util import check, check_l2, dev, gemm_modes
+
+gemm_mode = gemm_modes()
 
 pytestmark = pytest.mark.gpu
-TOL = 5e-5
-TOL_G = 3e-4
+# f32 mode (exact-f32 MFMA): element-wise max error.  bf16x3 mode: outputs element-wise at a looser
+# bound, gradients by relative L2 norm (see gpu_util.check_l2 for why).
+TOLS = {'f32': (5e-5, 3e-4, 1e-3), 'bf16x3': (1e-3, 5e-3, 5e-3)}
+
+
+def gcheck(mode, name, got, ref, tol):
+    return check(name, got, ref, tol) if mode == 'f32' else check_l2(name, got, ref, tol)
 
 
 def _t(g, k, grad=False):
     return torch.from_numpy(g[k]).to(dev()).requires_grad_(grad)
 
 
-def test_pcd_align_fixture():
+def test_pcd_align_fixture(gemm_mode):
+    TOL, TOL_G, _ = TOLS[gemm_mode]
     from realvsr_amd.archs.EDVR_arch import PCD_Align
     g = load_golden('pcd_align')
     pcd = PCD_Align(nf=int(g['nf']), groups=int(g['groups']))
@@ -26,13 +34,14 @@ def test_pcd_align_fixture():
     out.backward(_t(g, 'gout'))
     check('out', out, torch.from_numpy(g['out']), TOL)
     for l in range(3):
-        check('gnbr%d' % l, nbr[l].grad, torch.from_numpy(g['gnbr%d' % l]), TOL_G)
-        check('gref%d' % l, ref[l].grad, torch.from_numpy(g['gref%d' % l]), TOL_G)
+        gcheck(gemm_mode, 'gnbr%d' % l, nbr[l].grad, torch.from_numpy(g['gnbr%d' % l]), TOL_G)
+        gcheck(gemm_mode, 'gref%d' % l, ref[l].grad, torch.from_numpy(g['gref%d' % l]), TOL_G)
     for k, p in pcd.named_parameters():
-        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
+        gcheck(gemm_mode, 'grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
 
 
-def test_tsa_fusion_fixture():
+def test_tsa_fusion_fixture(gemm_mode):
+    TOL, TOL_G, _ = TOLS[gemm_mode]
     from realvsr_amd.archs.EDVR_arch import TSA_Fusion
     g = load_golden('tsa_fusion')
     tsa = TSA_Fusion(nf=16, nframes=3, center=1)
@@ -42,9 +51,9 @@ def test_tsa_fusion_fixture():
     out = tsa(al)
     out.backward(_t(g, 'gout'))
     check('out', out, torch.from_numpy(g['out']), TOL)
-    check('galigned', al.grad, torch.from_numpy(g['galigned']), TOL_G)
+    gcheck(gemm_mode, 'galigned', al.grad, torch.from_numpy(g['galigned']), TOL_G)
     for k, p in tsa.named_parameters():
-        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
+        gcheck(gemm_mode, 'grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_G)
 
 
 def _loss(out, gt):
@@ -52,7 +61,8 @@ def _loss(out, gt):
     return L.LapPyrLoss(3, 'cb', 'cb', 'mean')(out[:, 0:1], gt[:, 0:1]) + L.CharbonnierLoss()(out[:, 1:3], gt[:, 1:3])
 
 
-def test_edvr_tsa_fixture():
+def test_edvr_tsa_fixture(gemm_mode):
+    TOL, _, TOL_P = TOLS[gemm_mode]
     from realvsr_amd.archs.EDVR_arch import EDVR
     g = load_golden('edvr_tsa')
     net = EDVR(nf=16, nc=3, nframes=3, groups=4, front_RBs=2, back_RBs=2, w_TSA=True)
@@ -62,14 +72,15 @@ def test_edvr_tsa_fixture():
     check('out', out, torch.from_numpy(g['out']), TOL)
     loss = _loss(out, _t(g, 'gt'))
     loss.backward()
-    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss'])), (loss.item(), float(g['loss']))
+    assert abs(loss.item() - float(g['loss'])) <= (1e-5 if gemm_mode == 'f32' else 1e-4) * abs(float(g['loss'])), (loss.item(), float(g['loss']))
     gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item()
-    assert abs(gnorm - float(g['gnorm'])) <= 1e-3 * float(g['gnorm']), (gnorm, float(g['gnorm']))
+    assert abs(gnorm - float(g['gnorm'])) <= (1e-3 if gemm_mode == 'f32' else 5e-3) * float(g['gnorm']), (gnorm, float(g['gnorm']))
     for k, p in net.named_parameters():
-        check('grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), 1e-3)
+        gcheck(gemm_mode, 'grad.' + k, p.grad, torch.from_numpy(g['grad.' + k]), TOL_P)
 
 
-def test_edvr_noup_fixture():
+def test_edvr_noup_fixture(gemm_mode):
+    TOL, _, TOL_P = TOLS[gemm_mode]
     from weights import fill_state_dict
     from realvsr_amd.archs.EDVR_arch import EDVR_NoUp
     g = load_golden('edvr_noup')
@@ -80,13 +91,14 @@ def test_edvr_noup_fixture():
     check('out', out, torch.from_numpy(g['out']), TOL)
     loss = _loss(out, _t(g, 'gt'))
     loss.backward()
-    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    assert abs(loss.item() - float(g['loss'])) <= (1e-5 if gemm_mode == 'f32' else 1e-4) * abs(float(g['loss']))
     grads = dict(net.named_parameters())
     for k in [k for k in g if k.startswith('grad.')]:
-        check(k, grads[k[5:]].grad, torch.from_numpy(g[k]), 1e-3)
+        gcheck(gemm_mode, k, grads[k[5:]].grad, torch.from_numpy(g[k]), TOL_P)
 
 
-def test_config1_vs_oracle_psnr():
+def test_config1_vs_oracle_psnr(gemm_mode):
+    TOL = TOLS[gemm_mode][0]
     """BASELINE config 1: one 5-frame 64x64 LR window, EDVR-M nf64 / 5 front / 10 back RBs / TSA, forward.
     HIP output vs the CPU oracle on identical weights and input; PSNR-Y as train.py:301-305."""
     from oracle import edvr_oracle as O
