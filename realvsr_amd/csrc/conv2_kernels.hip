@@ -238,3 +238,227 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
     DISPATCH2(1, 1, 2);
 #undef DISPATCH2
 }
+
+// ==========================================================================================
+// Weight gradient on the bf16 matrix cores (3x3, stride 1, Wout % 4 == 0; other cases use the
+// exact-f32 kernel of conv_kernels.hip).
+//
+//   gW[o][(tap, c)] = sum_px G[o][px] * X[c][px + tap],   G = grad_out (* act'), K = pixels.
+//
+// One workgroup = 8 waves, persistent over 4x32-pixel tiles for a fixed (64-row m-block, 64-channel
+// chunk): 2 M tiles x 18 N tiles (tap x channel-half) = 36 accumulator tiles, 5/4 per wave so that
+// the two waves sharing a SIMD (w, w+4) hold 9 between them.  Both operands want 8 consecutive
+// PIXELS per lane, which is the natural NCHW order: G and X tiles are staged with aligned 16-byte
+// global loads, split into bf16 hi/lo and kept pixel-contiguous in LDS; the +-1 column shift of a
+// tap is applied in registers (v_alignbit on the two loaded octets), the row shift is an address.
+// The X tile is stored from column x0-4 so that every 8-pixel group is 16-byte aligned in LDS.
+#define WG2_THREADS 512
+#define WG2_GP 272   // bytes per output-channel row of the G tile: 4 rows x 64 B + 16 B pad
+#define WG2_XP 496   // bytes per input-channel plane of the X tile: 6 rows x 80 B + 16 B pad
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// 8 bf16 starting `shift` (3, 4 or 5) elements into the 16 held by (a, b)
+template <int SHIFT>
+__device__ __forceinline__ bf16x8 take8(u32x4 a, u32x4 b) {
+    u32x4 r;
+    if (SHIFT == 4) {
+        r[0] = a[2]; r[1] = a[3]; r[2] = b[0]; r[3] = b[1];
+    } else if (SHIFT == 3) {
+        r[0] = __builtin_amdgcn_alignbit(a[2], a[1], 16);
+        r[1] = __builtin_amdgcn_alignbit(a[3], a[2], 16);
+        r[2] = __builtin_amdgcn_alignbit(b[0], a[3], 16);
+        r[3] = __builtin_amdgcn_alignbit(b[1], b[0], 16);
+    } else {
+        r[0] = __builtin_amdgcn_alignbit(a[3], a[2], 16);
+        r[1] = __builtin_amdgcn_alignbit(b[0], a[3], 16);
+        r[2] = __builtin_amdgcn_alignbit(b[1], b[0], 16);
+        r[3] = __builtin_amdgcn_alignbit(b[2], b[1], 16);
+    }
+    return as_bf16x8(r);
+}
+
+// one (dy) row of taps for one accumulator group: DXMASK selects which dx (bit 0..2) this wave owns
+template <int DXMASK>
+__device__ __forceinline__ void wg2_row(const unsigned char* xs_hi, const unsigned char* xs_lo, int xoff, bf16x8 ah,
+                                        bf16x8 al, f32x16* acc) {
+    const u32x4 h0 = *reinterpret_cast<const u32x4*>(xs_hi + xoff), h1 = *reinterpret_cast<const u32x4*>(xs_hi + xoff + 16);
+    const u32x4 l0 = *reinterpret_cast<const u32x4*>(xs_lo + xoff), l1 = *reinterpret_cast<const u32x4*>(xs_lo + xoff + 16);
+    int t = 0;
+    if (DXMASK & 1) {
+        const bf16x8 bh = take8<3>(h0, h1), bl = take8<3>(l0, l1);
+        acc[t] = mfma_bf16(ah, bh, acc[t]); acc[t] = mfma_bf16(ah, bl, acc[t]); acc[t] = mfma_bf16(al, bh, acc[t]);
+        ++t;
+    }
+    if (DXMASK & 2) {
+        const bf16x8 bh = take8<4>(h0, h1), bl = take8<4>(l0, l1);
+        acc[t] = mfma_bf16(ah, bh, acc[t]); acc[t] = mfma_bf16(ah, bl, acc[t]); acc[t] = mfma_bf16(al, bh, acc[t]);
+        ++t;
+    }
+    if (DXMASK & 4) {
+        const bf16x8 bh = take8<5>(h0, h1), bl = take8<5>(l0, l1);
+        acc[t] = mfma_bf16(ah, bh, acc[t]); acc[t] = mfma_bf16(ah, bl, acc[t]); acc[t] = mfma_bf16(al, bh, acc[t]);
+    }
+}
+
+__global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* gs_hi = smem_raw;                  // [64 o][WG2_GP]
+    unsigned char* gs_lo = gs_hi + 64 * WG2_GP;
+    unsigned char* xs_hi = gs_lo + 64 * WG2_GP;       // [64 c][WG2_XP]
+    unsigned char* xs_lo = xs_hi + 64 * WG2_XP;
+    float* bsum = reinterpret_cast<float*>(xs_lo + 64 * WG2_XP);  // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int mb = blockIdx.y, c0 = blockIdx.z * 64;
+    const int Ctot = p.x.a.C + p.x.b.C, C1 = p.x.a.C;
+    const int H = p.x.a.Hs, W = p.x.a.Ws;  // stride 1, pad 1: Hout == H, Wout == W
+    // wave -> (M tile, channel half, first/second half of the 9 taps)
+    const int m = wave & 1, chalf = (wave >> 1) & 1, second = wave >> 2;
+    const bool m_live = (mb * 64 + m * 32) < p.Co;
+    const bool do_bias = p.bpart != nullptr && blockIdx.z == 0;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = zero16();
+    if (tid < 64) bsum[tid] = 0.f;
+    __syncthreads();
+
+    const int ntiles = p.B * p.nty * p.ntx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.P) {
+        const int b = tile / (p.nty * p.ntx);
+        const int trem = tile - b * (p.nty * p.ntx);
+        const int ty = trem / p.ntx, tx = trem - ty * p.ntx;
+        const int y0 = ty * 4, x0 = tx * 32;
+        // ---- G tile: 64 o x 4 rows x 4 octets
+        for (int it = tid; it < 64 * 16; it += WG2_THREADS) {
+            const int q = it & 3, row = (it >> 2) & 3, ol = it >> 4;
+            const int o = mb * 64 + ol, gy = y0 + row, gx = x0 + 8 * q;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (o < p.Co && gy < H && gx < W) {
+                if (p.g.mode == 0) {
+                    const size_t idx = (((size_t)b * p.Co + o) * H + gy) * W + gx;
+                    const float4 a0 = *reinterpret_cast<const float4*>(p.g.p + idx);
+                    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
+                    if (gx + 4 < W) {
+                        const float4 a1 = *reinterpret_cast<const float4*>(p.g.p + idx + 4);
+                        v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+                    }
+                    if (p.g.act != nullptr) {
+                        const float4 s0 = *reinterpret_cast<const float4*>(p.g.act + idx);
+                        v[0] *= s0.x > 0.f ? 1.f : p.g.slope; v[1] *= s0.y > 0.f ? 1.f : p.g.slope;
+                        v[2] *= s0.z > 0.f ? 1.f : p.g.slope; v[3] *= s0.w > 0.f ? 1.f : p.g.slope;
+                        if (gx + 4 < W) {
+                            const float4 s1 = *reinterpret_cast<const float4*>(p.g.act + idx + 4);
+                            v[4] *= s1.x > 0.f ? 1.f : p.g.slope; v[5] *= s1.y > 0.f ? 1.f : p.g.slope;
+                            v[6] *= s1.z > 0.f ? 1.f : p.g.slope; v[7] *= s1.w > 0.f ? 1.f : p.g.slope;
+                        }
+                    }
+                } else {  // mode 2: stored (Co/4, 2H, 2W) pixel-shuffled; 8 virtual px = 16 stored floats, every other one
+                    const size_t idx = (((size_t)b * (p.Co >> 2) + (o >> 2)) * (2 * H) + 2 * gy + ((o >> 1) & 1)) * (size_t)(2 * W) + 2 * gx;
+                    const int sx = o & 1;
+#pragma unroll
+                    for (int h4 = 0; h4 < 4; ++h4) {
+                        if (gx + 2 * h4 < W) {
+                            const float4 a = *reinterpret_cast<const float4*>(p.g.p + idx + 4 * h4);
+                            float e0 = sx ? a.y : a.x, e1 = sx ? a.w : a.z;
+                            if (p.g.act != nullptr) {
+                                const float4 s = *reinterpret_cast<const float4*>(p.g.act + idx + 4 * h4);
+                                e0 *= (sx ? s.y : s.x) > 0.f ? 1.f : p.g.slope;
+                                e1 *= (sx ? s.w : s.z) > 0.f ? 1.f : p.g.slope;
+                            }
+                            v[2 * h4] = e0;
+                            v[2 * h4 + 1] = e1;
+                        }
+                    }
+                }
+            }
+            if (do_bias) {
+                const float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                atomicAdd(&bsum[ol], s);
+            }
+            bf16x8 h8, l8;
+            split8(v, h8, l8);
+            const int off = ol * WG2_GP + row * 64 + q * 16;
+            *reinterpret_cast<bf16x8*>(gs_hi + off) = h8;
+            *reinterpret_cast<bf16x8*>(gs_lo + off) = l8;
+        }
+        // ---- X tile: 64 c x 6 rows x 5 octets, columns x0-4 .. x0+35
+        for (int it = tid; it < 64 * 30; it += WG2_THREADS) {
+            const int cl = it / 30, rem = it - cl * 30;
+            const int row = rem / 5, q = rem - row * 5;
+            const int c = c0 + cl, gy = y0 - 1 + row, gx = x0 - 4 + 8 * q;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (c < Ctot && gy >= 0 && gy < H) {
+                const float* src = c < C1 ? p.x.a.p + ((size_t)b * C1 + c) * H * W : p.x.b.p + ((size_t)b * (Ctot - C1) + (c - C1)) * H * W;
+                src += (size_t)gy * W;
+                if (gx >= 0 && gx < W) {
+                    const float4 a = *reinterpret_cast<const float4*>(src + gx);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                }
+                if (gx + 4 >= 0 && gx + 4 < W) {
+                    const float4 a = *reinterpret_cast<const float4*>(src + gx + 4);
+                    v[4] = a.x; v[5] = a.y; v[6] = a.z; v[7] = a.w;
+                }
+            }
+            bf16x8 h8, l8;
+            split8(v, h8, l8);
+            const int off = cl * WG2_XP + row * 80 + q * 16;
+            *reinterpret_cast<bf16x8*>(xs_hi + off) = h8;
+            *reinterpret_cast<bf16x8*>(xs_lo + off) = l8;
+        }
+        __syncthreads();
+        if (m_live) {
+#pragma unroll 2
+            for (int ks = 0; ks < 8; ++ks) {
+                const int row = ks >> 1, cb = (ks & 1) * 16 + 8 * hi;  // this lane's 8 pixels: row, cols cb..cb+7
+                const int goff = (m * 32 + lo) * WG2_GP + row * 64 + cb * 2;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(gs_hi + goff);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(gs_lo + goff);
+                // X octet pair holding stored cols cb .. cb+15 (= image cols x0-4+cb ..); tap dx needs +3+dx
+                const int xbase = (chalf * 32 + lo) * WG2_XP + cb * 2;
+                if (!second) {  // taps (0,0) (0,1) (0,2) (1,0) (1,1)
+                    wg2_row<7>(xs_hi, xs_lo, xbase + (row + 0) * 80, ah, al, acc + 0);
+                    wg2_row<3>(xs_hi, xs_lo, xbase + (row + 1) * 80, ah, al, acc + 3);
+                } else {        // taps (1,2) (2,0) (2,1) (2,2)
+                    wg2_row<4>(xs_hi, xs_lo, xbase + (row + 1) * 80, ah, al, acc + 0);
+                    wg2_row<7>(xs_hi, xs_lo, xbase + (row + 2) * 80, ah, al, acc + 1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (m_live) {
+        const int c = c0 + chalf * 32 + lo;
+        const int ntap = second ? 4 : 5, tap0 = second ? 5 : 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i >= ntap || c >= Ctot) continue;
+            const int tap = tap0 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mb * 64 + m * 32 + drow(r, hi);
+                if (o < p.Co) p.part[(((size_t)blockIdx.x * p.Co + o) * Ctot + c) * 9 + tap] = acc[i][r];
+            }
+        }
+    }
+    if (do_bias && tid < 64) {
+        const int o = mb * 64 + tid;
+        if (o < p.Co) p.bpart[(size_t)blockIdx.x * p.Co + o] = bsum[tid];
+    }
+}
+
+int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_t st) {
+    const size_t lds = 2 * 64 * WG2_GP + 2 * 64 * WG2_XP + 64 * sizeof(float);
+    if (set_lds(conv_wgrad2_kernel, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(p.P, gy, gz), dim3(WG2_THREADS), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}

@@ -386,7 +386,10 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (ksize == 3 && stride == 1)
+    const bool aligned16 = ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)gout) | ((uintptr_t)gact)) & 15) == 0;
+    if (rvsr_g_gemm_mode == 0 && ksize == 3 && stride == 1 && (Wout % 4) == 0 && aligned16)
+        rc = rvsr_launch_conv_wgrad2(p, gy, gz, st);
+    else if (ksize == 3 && stride == 1)
         rc = launch_wgrad<3, 1, 64>(p, gy, gz, st);
     else if (ksize == 3)
         rc = launch_wgrad<3, 2, 32>(p, gy, gz, st);
