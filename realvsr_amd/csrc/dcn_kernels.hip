@@ -124,6 +124,18 @@ __device__ __forceinline__ void dcn_build_cols(const DcnGeom& d, int b, int c0, 
     }
 }
 
+// add `v` to plane[idx] (idx = y*W + x): through the LDS tile when (y, x) falls inside it
+__device__ __forceinline__ void dcn_scatter(float* gplane, float* ltile, int idx, float v, int W, int ty0, int tx0,
+                                            int gth, int gtw) {
+    if (v == 0.f) return;
+    const int y = idx / W, x = idx - y * W;
+    const int ly = y - ty0, lx = x - tx0;
+    if (ly >= 0 && ly < gth && lx >= 0 && lx < gtw)
+        __hip_atomic_fetch_add(ltile + ly * gtw + lx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        atomicAdd(gplane + idx, v);
+}
+
 // ------------------------------------------------------------------------------------------
 struct DcnFwdParams {
     DcnGeom d;
@@ -214,6 +226,10 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdI
     float* gs = smem;                            // [CoP][128]     grad_output tile
     float* ws = gs + CoP * DCN_NPX;              // [CoP][72]      weight slice (natural layout)
     float* cg = ws + CoP * DCN_KC;               // [72][128]      col_grad tile
+    // grad_input accumulation tile for the chunk's 8 channels: rows y0-1-R .. y0+4+R, cols x0-1-R .. x0+32+R
+    // (stride 1 / dilation 1 geometry; other geometries simply hit the global-atomic fallback more often)
+    constexpr int GR = 4, GTH = 4 + 2 * GR + 2, GTW = 32 + 2 * GR + 2;
+    float* gxt = cg + DCN_KC * DCN_NPX;          // [8][GTH][GTW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
     const int x0 = tx * 32, y0 = ty * 4, b = blockIdx.z;
@@ -229,6 +245,8 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdI
     const int chs = CHS > 0 ? CHS : (d.cpg < DCN_CC ? d.cpg : DCN_CC);
     const int nslots = DCN_CC / chs;
     const int nitems = DCN_NPX * 9 * nslots;
+    const int ty0 = y0 * d.stride - d.pad - GR, tx0 = x0 * d.stride - d.pad - GR;  // image coords of tile cell (0,0)
+    for (int e = tid; e < DCN_CC * GTH * GTW; e += RVSR_WG) gxt[e] = 0.f;
 
     for (int c0 = 0; c0 < d.C; c0 += DCN_CC) {
 #pragma unroll 4
@@ -289,11 +307,13 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdI
                     gy += (hx * (x10 - x00) + s.lx * (x11 - x01)) * t;
                     gxo += (hy * (x01 - x00) + s.ly * (x11 - x10)) * t;
                     // grad_input (kernel.cu:674-691): scatter to the <=4 valid corners
+                    // LDS-privatised: corners inside the tile go to ds_add_f32, the rest to global atomics
                     float* gp = p.gx + ((size_t)b * d.C + c) * HW;
-                    if (s.w00 != 0.f) atomicAdd(gp + s.i00, s.w00 * t);
-                    if (s.w01 != 0.f) atomicAdd(gp + s.i01, s.w01 * t);
-                    if (s.w10 != 0.f) atomicAdd(gp + s.i10, s.w10 * t);
-                    if (s.w11 != 0.f) atomicAdd(gp + s.i11, s.w11 * t);
+                    float* lt = gxt + (slot * chs + j) * (GTH * GTW);
+                    dcn_scatter(gp, lt, s.i00, s.w00 * t, d.W, ty0, tx0, GTH, GTW);
+                    dcn_scatter(gp, lt, s.i01, s.w01 * t, d.W, ty0, tx0, GTH, GTW);
+                    dcn_scatter(gp, lt, s.i10, s.w10 * t, d.W, ty0, tx0, GTH, GTW);
+                    dcn_scatter(gp, lt, s.i11, s.w11 * t, d.W, ty0, tx0, GTH, GTW);
                 }
             }
             if (d.mask_logit) gm *= s.m * (1.f - s.m);
@@ -308,6 +328,19 @@ __global__ __launch_bounds__(RVSR_WG, 1) void dcn_bwd_input_kernel(const DcnBwdI
                 go[0] += gy;
                 go[hw] += gxo;
                 gk[0] += gm;
+            }
+        }
+        __syncthreads();
+        // flush the accumulation tile (one global atomic per touched cell instead of one per sample corner)
+        for (int e = tid; e < DCN_CC * GTH * GTW; e += RVSR_WG) {
+            const float v = gxt[e];
+            if (v != 0.f) {
+                gxt[e] = 0.f;
+                const int cc = e / (GTH * GTW), rem = e - cc * (GTH * GTW);
+                const int yy = ty0 + rem / GTW, xx = tx0 + rem % GTW;
+                const int c = c0 + cc;
+                if (c < d.C && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W)
+                    atomicAdd(p.gx + ((size_t)b * d.C + c) * HW + (size_t)yy * d.W + xx, v);
             }
         }
         __syncthreads();
@@ -473,7 +506,7 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         DcnBwdInParams p;
         p.d = d; p.w = weight; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
         const int CoP = (d.Co + 1) & ~1;
-        const size_t lds = sizeof(float) * ((size_t)CoP * DCN_NPX + (size_t)CoP * DCN_KC + DCN_KC * DCN_NPX);
+        const size_t lds = sizeof(float) * ((size_t)CoP * DCN_NPX + (size_t)CoP * DCN_KC + DCN_KC * DCN_NPX + DCN_CC * 14 * 42);
         if (lds > 160 * 1024) FAIL(RVSR_ERR_UNSUPPORTED, "dcn backward: channels_out %d needs %zu B of LDS", d.Co, lds);
         if (d.cpg % DCN_CC == 0) {
             if (set_lds(dcn_bwd_input_kernel<8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
