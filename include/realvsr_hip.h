@@ -48,13 +48,17 @@ int rvsr_get_gemm_mode(void);
  *   input (B,C,H,W)  weight (Co,C,kh,kw)  bias (Co) or NULL  offset (B,2*dg*kh*kw,Ho,Wo)
  *   mask (B,dg*kh*kw,Ho,Wo)  output (B,Co,Ho,Wo) -- fully overwritten.
  * The reference's `ones` / `columns` temporaries do not exist here (the column tile lives in LDS).
- * HIP path: kh = kw = 3, group = 1, isotropic stride/pad/dilation, C/dg dividing or a multiple of 8. */
+ * HIP path: kh = kw = 3, group = 1, isotropic stride/pad/dilation, C/dg dividing or a multiple of 8.
+ * workspace: rvsr_modulated_deform_conv_forward_workspace_bytes(channels, channels_out) bytes for
+ * the bf16 hi/lo re-packed weights of the bf16x3 kernel; NULL selects the exact-f32 kernel. */
+size_t rvsr_modulated_deform_conv_forward_workspace_bytes(int channels, int channels_out);
 int rvsr_modulated_deform_conv_forward(const float* input, const float* weight, const float* bias,
                                        const float* offset, const float* mask, float* output,
                                        int batch, int channels, int height, int width, int channels_out,
                                        int kernel_h, int kernel_w, int stride_h, int stride_w,
                                        int pad_h, int pad_w, int dilation_h, int dilation_w,
-                                       int group, int deformable_group, int with_bias, void* stream);
+                                       int group, int deformable_group, int with_bias,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Replaces modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:571-685) + the col2im /
  * col2im_coord / im2col kernels (deform_conv_cuda_kernel.cu:571-767).
@@ -82,7 +86,7 @@ int rvsr_modulated_deform_conv_backward(const float* input, const float* weight,
 int rvsr_dcn_pack_forward(const float* input, const float* weight, const float* bias, const float* om,
                           float* output, int batch, int channels, int height, int width, int channels_out,
                           int stride, int pad, int dilation, int deformable_group, int act, float slope,
-                          void* stream);
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* act_out (NULL or the saved activation output) fuses the activation derivative into the
  * grad_output load.  grad_om (B,3*dg*9,Ho,Wo) is overwritten (d/d logit for the mask part);
  * grad_input zero on entry; grad_weight/grad_bias accumulated. */

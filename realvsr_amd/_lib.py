@@ -17,10 +17,11 @@ c_int, c_float, c_double, c_size = ctypes.c_int, ctypes.c_float, ctypes.c_double
 # name -> (restype, argtypes); must list every symbol declared in include/realvsr_hip.h
 SIGNATURES = {
     'rvsr_last_error': (ctypes.c_char_p, []),
-    'rvsr_modulated_deform_conv_forward': (c_int, [c_fp] * 6 + [c_int] * 16 + [c_fp]),
+    'rvsr_modulated_deform_conv_forward': (c_int, [c_fp] * 6 + [c_int] * 16 + [c_fp, c_size, c_fp]),
+    'rvsr_modulated_deform_conv_forward_workspace_bytes': (c_size, [c_int] * 2),
     'rvsr_modulated_deform_conv_backward_workspace_bytes': (c_size, [c_int] * 8),
     'rvsr_modulated_deform_conv_backward': (c_int, [c_fp] * 11 + [c_int] * 16 + [c_fp, c_size, c_fp]),
-    'rvsr_dcn_pack_forward': (c_int, [c_fp] * 5 + [c_int] * 10 + [c_float, c_fp]),
+    'rvsr_dcn_pack_forward': (c_int, [c_fp] * 5 + [c_int] * 10 + [c_float, c_fp, c_size, c_fp]),
     'rvsr_dcn_pack_backward': (c_int, [c_fp] * 5 + [c_float] + [c_fp] * 4 + [c_int] * 9 + [c_fp, c_size, c_fp]),
     'rvsr_conv2d_forward': (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_float, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                     c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,

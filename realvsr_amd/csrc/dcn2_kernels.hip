@@ -1,0 +1,213 @@
+// dcn2_kernels.hip -- modulated deformable convolution, second generation (gfx950).
+//
+// Forward: out[Co, px] = W[Co, (tap, c)] * col[(tap, c), px] where col = mask * bilinear(x).  The
+// column matrix is never stored anywhere -- not in HBM (reference: `columns`, 132.7 MB per call),
+// not in LDS: the lane that the matrix core expects to hold B[k-octet][pixel] *computes* those 8
+// values itself and feeds them straight into v_mfma_f32_32x32x16_bf16 (3-term bf16 split, see
+// bf16x3.h).  With K ordered (tap, channel) one k-octet = the 8 channels of one deformable group
+// slice at one tap, i.e. exactly the values that share one (dy, dx, mask) triple, so a lane does
+// one sampling-geometry computation + 4 corner fetches of 8 channels per MFMA k-step.
+//
+//   workgroup   = TH waves = TH rows x 32 pixels of output, all Co (M tiles in registers)
+//   K chunk     = 16 input channels: k-step = (tap, 16 channels); lane half hi picks the octet
+//   LDS         = x tile for the chunk, channel-quad-major [octet][half][row][col][4] f32 with a
+//                 halo of R pixels (corner fetch = 2 conflict-free ds_read_b128), + the packed
+//                 bf16 hi/lo weight slice of the chunk (linear copy of the pre-packed image).
+//   out-of-tile samples (|offset| > R) fall back to global loads for that lane -- correct for any
+//   offset, fast for the common small ones.
+//   offsets / mask are read exactly once, coalesced along W; sigmoid of the mask logits in-kernel.
+#include "bf16x3.h"
+#include "dcn_common.h"
+
+#define D2_R 3  // halo radius (pixels) of the LDS x tile beyond the 3x3 footprint
+
+template <int TH, int MT>
+__global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
+    constexpr int NT = TH * 64;
+    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    constexpr int MP = MT * 32, WVEC = 9 * 2 * MP;  // 16-byte vectors per weight part
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);           // [2 octets][2 halves][NPOS]
+    bf16x8* ws_hi = reinterpret_cast<bf16x8*>(xt + 4 * NPOS);   // [9 taps][2 octets][MP]
+    bf16x8* ws_lo = ws_hi + WVEC;
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
+    const int x0 = tx * 32, y0 = ty * TH, mb = blockIdx.y, b = blockIdx.z;
+    const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;  // image coords of tile (0,0)
+    const int nchunks = (d.C + 15) / 16;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int oy = y0 + wave, ox = x0 + lo;
+    const bool px_ok = oy < d.Ho && ox < d.Wo;
+    const size_t pix = (size_t)oy * d.Wo + ox;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = zero16();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * 16;
+        {   // weight slice: linear copy of the pre-packed LDS image (hi block, then lo block)
+            const bf16x8* src = wpack + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
+#pragma unroll 4
+            for (int e = tid; e < 2 * WVEC; e += NT) ws_hi[e] = src[e];
+        }
+        // x tile of the chunk's 16 channels: item = (quad of 4 channels, position)
+        for (int it = tid; it < 4 * NPOS; it += NT) {
+            const int quad = it / NPOS, pos = it - quad * NPOS;
+            const int r = pos / TC, s = pos - r * TC;
+            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
+                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
+                v.x = src[0];
+                if (cb + 1 < d.C) v.y = src[HW];
+                if (cb + 2 < d.C) v.z = src[2 * HW];
+                if (cb + 3 < d.C) v.w = src[3 * HW];
+            }
+            xt[it] = v;
+        }
+        __syncthreads();
+
+        const int cb8 = c0 + 8 * hi;              // first channel of this lane's octet
+        const bool oct_ok = px_ok && cb8 < d.C;
+        const int g = oct_ok ? cb8 / d.cpg : 0;
+        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pix;
+        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pix;
+        const float4* xq0 = xt + (2 * hi) * NPOS;  // channels cb8..cb8+3
+        const float4* xq1 = xq0 + NPOS;            // channels cb8+4..cb8+7
+        float n_dy = 0.f, n_dx = 0.f, n_m = 0.f;
+        if (oct_ok) {
+            n_dy = offp[0];
+            n_dx = offp[hw];
+            n_m = mskp[0];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float dy = n_dy, dx = n_dx;
+            float m = n_m;
+            if (tap < 8 && oct_ok) {  // prefetch the next tap's offsets/mask under this tap's math
+                n_dy = offp[(size_t)(2 * tap + 2) * hw];
+                n_dx = offp[(size_t)(2 * tap + 3) * hw];
+                n_m = mskp[(size_t)(tap + 1) * hw];
+            }
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (oct_ok) {
+                if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
+                const float y = (float)(oy * d.stride - d.pad + (tap / 3) * d.dil) + dy;
+                const float x = (float)(ox * d.stride - d.pad + (tap % 3) * d.dil) + dx;
+                if (y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W) {
+                    const float fy = floorf(y), fx = floorf(x);
+                    const int yi = (int)fy, xi = (int)fx;
+                    const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+                    const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                    const float w00 = (vy0 && vx0) ? hy * hx : 0.f, w01 = (vy0 && vx1) ? hy * lx : 0.f;
+                    const float w10 = (vy1 && vx0) ? ly * hx : 0.f, w11 = (vy1 && vx1) ? ly * lx : 0.f;
+                    const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1;
+                    const int cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                    const int r0 = cy0 - ty0, r1 = cy1 - ty0, s0 = cx0 - tx0, s1 = cx1 - tx0;
+                    if (r0 >= 0 && r1 < TR && s0 >= 0 && s1 < TC) {  // all four corners inside the LDS tile
+                        const int p00 = r0 * TC + s0, p01 = r0 * TC + s1, p10 = r1 * TC + s0, p11 = r1 * TC + s1;
+                        const float4 a00 = xq0[p00], b00 = xq1[p00], a01 = xq0[p01], b01 = xq1[p01];
+                        const float4 a10 = xq0[p10], b10 = xq1[p10], a11 = xq0[p11], b11 = xq1[p11];
+                        v[0] = w00 * a00.x + w01 * a01.x + w10 * a10.x + w11 * a11.x;
+                        v[1] = w00 * a00.y + w01 * a01.y + w10 * a10.y + w11 * a11.y;
+                        v[2] = w00 * a00.z + w01 * a01.z + w10 * a10.z + w11 * a11.z;
+                        v[3] = w00 * a00.w + w01 * a01.w + w10 * a10.w + w11 * a11.w;
+                        v[4] = w00 * b00.x + w01 * b01.x + w10 * b10.x + w11 * b11.x;
+                        v[5] = w00 * b00.y + w01 * b01.y + w10 * b10.y + w11 * b11.y;
+                        v[6] = w00 * b00.z + w01 * b01.z + w10 * b10.z + w11 * b11.z;
+                        v[7] = w00 * b00.w + w01 * b01.w + w10 * b10.w + w11 * b11.w;
+                    } else {  // large offset: fetch this lane's corners from global memory
+                        const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                        const float* pl = d.x + ((size_t)b * d.C + cb8) * HW;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (cb8 + j < d.C) {
+                                const float* q = pl + (size_t)j * HW;
+                                v[j] = w00 * q[i00] + w01 * q[i01] + w10 * q[i10] + w11 * q[i11];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= m;
+                }
+            }
+            bf16x8 bh, bl;
+            split8(v, bh, bl);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 ah = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
+                const bf16x8 al = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
+                acc[mt] = mfma_bf16(ah, bh, acc[mt]);
+                acc[mt] = mfma_bf16(ah, bl, acc[mt]);
+                acc[mt] = mfma_bf16(al, bh, acc[mt]);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (oy >= d.Ho) return;
+    const bool has_bias = p.bias != nullptr;
+    const float* bp = has_bias ? p.bias : p.w;
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = mb * MP + mt * 32 + drow(r, hi);
+            const bool ok = ox < d.Wo && o < d.Co;
+            const int oc = ok ? o : 0;
+            float v = acc[mt][r];
+            const float bb = bp[oc];
+            v += has_bias ? bb : 0.f;
+            v = v > 0.f ? v : v * neg;
+            if (ok) p.out[((size_t)b * d.Co + oc) * hw + pix] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static void fwd2_geom(int Co, int C, int& mt, int& nchunks, int& nmb) {
+    mt = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+    nchunks = (C + 15) / 16;
+    nmb = (Co + mt * 32 - 1) / (mt * 32);
+}
+
+size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C) {
+    int mt, nchunks, nmb;
+    fwd2_geom(Co, C, mt, nchunks, nmb);
+    return (size_t)nmb * nchunks * 2 * 9 * 2 * (mt * 32) * 16;
+}
+
+template <int TH, int MT>
+static int launch_dcn_fwd2(const DcnFwdParams& p, const bf16x8* wpack, hipStream_t st) {
+    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    const size_t lds = (size_t)16 * (4 * TR * TC + 2 * 9 * 2 * MT * 32);
+    auto k = dcn_fwd2_kernel<TH, MT>;
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd2: cannot reserve %zu B of LDS", lds);
+    const DcnGeom& d = p.d;
+    dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), (d.Co + MT * 32 - 1) / (MT * 32), d.B);
+    hipLaunchKernelGGL(k, grid, dim3(TH * 64), lds, st, p, wpack);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd2 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const DcnGeom& d = p.d;
+    if (d.cpg % 8 != 0) return RVSR_ERR_UNSUPPORTED;  // a k-octet must lie inside one deformable group
+    int mt, nchunks, nmb;
+    fwd2_geom(d.Co, d.C, mt, nchunks, nmb);
+    const size_t need = rvsr_dcn_fwd2_workspace_bytes(d.Co, d.C);
+    if (!workspace || workspace_bytes < need) FAIL(RVSR_ERR_WORKSPACE, "dcn forward: workspace %zu B < %zu B", workspace_bytes, need);
+    const size_t total = (size_t)nmb * nchunks * 9 * 2 * (mt * 32);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, d.Co,
+                       d.C, 9, mt * 32, 1, nchunks, nmb, 0);
+    const bf16x8* wp = (const bf16x8*)workspace;
+    if (mt == 1) return launch_dcn_fwd2<8, 1>(p, wp, st);
+    if (mt == 2) return launch_dcn_fwd2<8, 2>(p, wp, st);
+    return launch_dcn_fwd2<8, 4>(p, wp, st);
+}

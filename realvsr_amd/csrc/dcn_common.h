@@ -1,0 +1,84 @@
+// dcn_common.h -- geometry / sampling helpers shared by dcn_kernels.hip (f32 MFMA) and dcn2_kernels.hip (bf16x3).
+#pragma once
+#include "rvsr_common.h"
+
+#define DCN_CC 8      // input channels per K chunk
+#define DCN_KC 72     // = DCN_CC * 9 column rows per chunk
+#define DCN_NPX 128   // pixels per tile (4 rows x 32)
+
+struct DcnGeom {
+    const float* x;       // (B, C, H, W)
+    const float* offset;  // (b * off_bs)[(g*18 + 2k + {0:dy,1:dx})][Ho][Wo]
+    const float* mask;    // (b * mask_bs)[(g*9 + k)][Ho][Wo]
+    size_t off_bs, mask_bs;
+    int mask_logit;       // 1: mask holds logits, sigmoid applied here
+    int B, C, H, W, Co, Ho, Wo;
+    int stride, pad, dil, dg, cpg;
+    int ntx;
+};
+
+struct Samp {
+    float w00, w01, w10, w11;  // bilinear corner weights (0 for corners outside the image)
+    float ly, lx;
+    int i00, i01, i10, i11;    // clamped plane indices (always safe to load)
+    float m;                   // modulation mask
+    bool inside;
+    bool v00, v01, v10, v11;   // corner inside the image
+};
+
+// sampling geometry of tap k at output pixel (oy, ox) for deformable group g  (kernel.cu:594-618)
+__device__ __forceinline__ Samp dcn_sample(const DcnGeom& d, int b, int g, int k, int oy, int ox) {
+    const size_t hw = (size_t)d.Ho * d.Wo;
+    const size_t p = (size_t)oy * d.Wo + ox;
+    const float* ob = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * k) * hw + p;
+    const float dy = ob[0], dx = ob[hw];
+    float m = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + k) * hw + p];
+    if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
+    const float y = (float)(oy * d.stride - d.pad + (k / 3) * d.dil) + dy;
+    const float x = (float)(ox * d.stride - d.pad + (k % 3) * d.dil) + dx;
+    Samp s;
+    s.m = m;
+    s.inside = (y > -1.f) && (x > -1.f) && (y < (float)d.H) && (x < (float)d.W);
+    s.w00 = s.w01 = s.w10 = s.w11 = 0.f;
+    s.ly = s.lx = 0.f;
+    s.i00 = s.i01 = s.i10 = s.i11 = 0;
+    s.v00 = s.v01 = s.v10 = s.v11 = false;
+    if (s.inside) {
+        const float fy = floorf(y), fx = floorf(x);
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+        s.ly = ly;
+        s.lx = lx;
+        const bool vy0 = y0 >= 0, vy1 = y1 <= d.H - 1, vx0 = x0 >= 0, vx1 = x1 <= d.W - 1;
+        const int cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : d.H - 1, cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : d.W - 1;
+        s.i00 = cy0 * d.W + cx0;
+        s.i01 = cy0 * d.W + cx1;
+        s.i10 = cy1 * d.W + cx0;
+        s.i11 = cy1 * d.W + cx1;
+        s.v00 = vy0 && vx0;
+        s.v01 = vy0 && vx1;
+        s.v10 = vy1 && vx0;
+        s.v11 = vy1 && vx1;
+        s.w00 = s.v00 ? hy * hx : 0.f;
+        s.w01 = s.v01 ? hy * lx : 0.f;
+        s.w10 = s.v10 ? ly * hx : 0.f;
+        s.w11 = s.v11 ? ly * lx : 0.f;
+    }
+    return s;
+}
+
+
+struct DcnFwdParams {
+    DcnGeom d;
+    const float* w;     // (Co, C, 3, 3)
+    const float* bias;  // nullable
+    float* out;         // (B, Co, Ho, Wo)
+    int act;
+    float slope;
+};
+
+
+// bf16x3 forward (dcn2_kernels.hip); returns RVSR_ERR_UNSUPPORTED if the geometry is not covered
+size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C);
+int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st);
+extern int rvsr_g_gemm_mode;

@@ -21,70 +21,7 @@
 // explicit and the mask sigmoid (deform_conv.py:281-283) is then applied in-kernel.
 #include "rvsr_common.h"
 
-#define DCN_CC 8      // input channels per K chunk
-#define DCN_KC 72     // = DCN_CC * 9 column rows per chunk
-#define DCN_NPX 128   // pixels per tile (4 rows x 32)
-
-struct DcnGeom {
-    const float* x;       // (B, C, H, W)
-    const float* offset;  // (b * off_bs)[(g*18 + 2k + {0:dy,1:dx})][Ho][Wo]
-    const float* mask;    // (b * mask_bs)[(g*9 + k)][Ho][Wo]
-    size_t off_bs, mask_bs;
-    int mask_logit;       // 1: mask holds logits, sigmoid applied here
-    int B, C, H, W, Co, Ho, Wo;
-    int stride, pad, dil, dg, cpg;
-    int ntx;
-};
-
-struct Samp {
-    float w00, w01, w10, w11;  // bilinear corner weights (0 for corners outside the image)
-    float ly, lx;
-    int i00, i01, i10, i11;    // clamped plane indices (always safe to load)
-    float m;                   // modulation mask
-    bool inside;
-    bool v00, v01, v10, v11;   // corner inside the image
-};
-
-// sampling geometry of tap k at output pixel (oy, ox) for deformable group g  (kernel.cu:594-618)
-__device__ __forceinline__ Samp dcn_sample(const DcnGeom& d, int b, int g, int k, int oy, int ox) {
-    const size_t hw = (size_t)d.Ho * d.Wo;
-    const size_t p = (size_t)oy * d.Wo + ox;
-    const float* ob = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * k) * hw + p;
-    const float dy = ob[0], dx = ob[hw];
-    float m = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + k) * hw + p];
-    if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
-    const float y = (float)(oy * d.stride - d.pad + (k / 3) * d.dil) + dy;
-    const float x = (float)(ox * d.stride - d.pad + (k % 3) * d.dil) + dx;
-    Samp s;
-    s.m = m;
-    s.inside = (y > -1.f) && (x > -1.f) && (y < (float)d.H) && (x < (float)d.W);
-    s.w00 = s.w01 = s.w10 = s.w11 = 0.f;
-    s.ly = s.lx = 0.f;
-    s.i00 = s.i01 = s.i10 = s.i11 = 0;
-    s.v00 = s.v01 = s.v10 = s.v11 = false;
-    if (s.inside) {
-        const float fy = floorf(y), fx = floorf(x);
-        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-        const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
-        s.ly = ly;
-        s.lx = lx;
-        const bool vy0 = y0 >= 0, vy1 = y1 <= d.H - 1, vx0 = x0 >= 0, vx1 = x1 <= d.W - 1;
-        const int cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : d.H - 1, cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : d.W - 1;
-        s.i00 = cy0 * d.W + cx0;
-        s.i01 = cy0 * d.W + cx1;
-        s.i10 = cy1 * d.W + cx0;
-        s.i11 = cy1 * d.W + cx1;
-        s.v00 = vy0 && vx0;
-        s.v01 = vy0 && vx1;
-        s.v10 = vy1 && vx0;
-        s.v11 = vy1 && vx1;
-        s.w00 = s.v00 ? hy * hx : 0.f;
-        s.w01 = s.v01 ? hy * lx : 0.f;
-        s.w10 = s.v10 ? ly * hx : 0.f;
-        s.w11 = s.v11 ? ly * lx : 0.f;
-    }
-    return s;
-}
+#include "dcn_common.h"
 
 // Build the column tile of channel chunk [c0, c0+8) for the 128 pixels of a tile.
 // COLT == false: col[k * 128 + px]      (k-major; B operand of the forward GEMM)
@@ -137,15 +74,6 @@ __device__ __forceinline__ void dcn_scatter(float* gplane, float* ltile, int idx
 }
 
 // ------------------------------------------------------------------------------------------
-struct DcnFwdParams {
-    DcnGeom d;
-    const float* w;     // (Co, C, 3, 3)
-    const float* bias;  // nullable
-    float* out;         // (B, Co, Ho, Wo)
-    int act;
-    float slope;
-};
-
 template <int MT, int CHS>
 __global__ __launch_bounds__(RVSR_WG, 2) void dcn_fwd_kernel(const DcnFwdParams p) {
     constexpr int MP = MT * 32, MPP = MP + 1;
@@ -448,9 +376,14 @@ static int fill_geom(DcnGeom& d, const float* x, const float* offset, size_t off
     return RVSR_OK;
 }
 
-static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, float* out, int act, float slope, hipStream_t st) {
+static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, float* out, int act, float slope,
+                            void* workspace, size_t workspace_bytes, hipStream_t st) {
     DcnFwdParams p;
     p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act; p.slope = slope;
+    if (rvsr_g_gemm_mode == 0 && workspace != nullptr) {  // bf16x3 second-generation kernel
+        const int rc = rvsr_launch_dcn_fwd2(p, workspace, workspace_bytes, st);
+        if (rc != RVSR_ERR_UNSUPPORTED) return rc;
+    }
     const int nty = (d.Ho + 3) / 4;
     const bool c8 = d.cpg % DCN_CC == 0;  // every chunk of 8 channels shares one offset set
 #define LAUNCH_FWD(MT)                                                                                              \
@@ -482,6 +415,10 @@ static int bww_P(int ntiles, int gy, int gz) {
     if (P < 1) P = 1;
     if (P > ntiles) P = ntiles;
     return P;
+}
+
+extern "C" size_t rvsr_modulated_deform_conv_forward_workspace_bytes(int channels, int channels_out) {
+    return rvsr_dcn_fwd2_workspace_bytes(channels_out, channels);
 }
 
 extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch, int channels, int height, int width,
@@ -547,7 +484,7 @@ extern "C" int rvsr_modulated_deform_conv_forward(const float* input, const floa
                                                   int channels, int height, int width, int channels_out, int kernel_h,
                                                   int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
                                                   int dilation_h, int dilation_w, int group, int deformable_group,
-                                                  int with_bias, void* stream) {
+                                                  int with_bias, void* workspace, size_t workspace_bytes, void* stream) {
     DcnGeom d;
     const char* why = "";
     if (!weight || !output) FAIL(RVSR_ERR_BAD_ARG, "modulated_deform_conv_forward: null weight/output");
@@ -556,7 +493,7 @@ extern "C" int rvsr_modulated_deform_conv_forward(const float* input, const floa
     if (rc) FAIL(rc, "modulated_deform_conv_forward: %s", why);
     d.off_bs = (size_t)2 * 9 * deformable_group * d.Ho * d.Wo;
     d.mask_bs = (size_t)9 * deformable_group * d.Ho * d.Wo;
-    return dcn_forward_impl(d, weight, with_bias ? bias : nullptr, output, 0, 0.f, (hipStream_t)stream);
+    return dcn_forward_impl(d, weight, with_bias ? bias : nullptr, output, 0, 0.f, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int rvsr_modulated_deform_conv_backward(const float* input, const float* weight, const float* bias,
@@ -586,7 +523,7 @@ extern "C" int rvsr_modulated_deform_conv_backward(const float* input, const flo
 extern "C" int rvsr_dcn_pack_forward(const float* input, const float* weight, const float* bias, const float* om,
                                      float* output, int batch, int channels, int height, int width, int channels_out,
                                      int stride, int pad, int dilation, int deformable_group, int act, float slope,
-                                     void* stream) {
+                                     void* workspace, size_t workspace_bytes, void* stream) {
     DcnGeom d;
     const char* why = "";
     if (!weight || !output) FAIL(RVSR_ERR_BAD_ARG, "dcn_pack_forward: null weight/output");
@@ -596,7 +533,7 @@ extern "C" int rvsr_dcn_pack_forward(const float* input, const float* weight, co
     const size_t hw = (size_t)d.Ho * d.Wo;
     d.off_bs = d.mask_bs = (size_t)27 * deformable_group * hw;
     d.mask = om + (size_t)18 * deformable_group * hw;
-    return dcn_forward_impl(d, weight, bias, output, act, slope, (hipStream_t)stream);
+    return dcn_forward_impl(d, weight, bias, output, act, slope, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int rvsr_dcn_pack_backward(const float* input, const float* weight, const float* om, const float* grad_output,

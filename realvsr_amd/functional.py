@@ -149,9 +149,11 @@ class ModulatedDeformConvFunction(Function):
         Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
         output = input.new_empty(B, Co, Ho, Wo)
         L = _lib.lib()
+        ws = _workspace(L.rvsr_modulated_deform_conv_forward_workspace_bytes(C, Co), input.device)
         _lib.check(L.rvsr_modulated_deform_conv_forward(
             _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(output), B, C, H, W, Co, kh, kw, stride, stride,
-            padding, padding, dilation, dilation, groups, deformable_groups, int(bias is not None), _stream()),
+            padding, padding, dilation, dilation, groups, deformable_groups, int(bias is not None), _p(ws), ws.numel(),
+            _stream()),
             'modulated_deform_conv_forward')
         ctx.save_for_backward(input, offset, mask, weight, bias)
         return output
@@ -202,8 +204,10 @@ class _DcnPackFused(Function):
             raise RuntimeError('conv_offset_mask output has shape %s, expected %s' % (tuple(om.shape), (B, 27 * dg, Ho, Wo)))
         out = x.new_empty(B, Co, Ho, Wo)
         L = _lib.lib()
+        ws = _workspace(L.rvsr_modulated_deform_conv_forward_workspace_bytes(C, Co), x.device)
         _lib.check(L.rvsr_dcn_pack_forward(_p(x), _p(weight), _p(bias), _p(om), _p(out), B, C, H, W, Co, stride,
-                                           padding, dilation, dg, act, slope, _stream()), 'dcn_pack_forward')
+                                           padding, dilation, dg, act, slope, _p(ws), ws.numel(), _stream()),
+                   'dcn_pack_forward')
         ctx.cfg = (stride, padding, dilation, dg, act, slope, bias is not None)
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
         return out

@@ -30,16 +30,17 @@ def _run_oracle(x, off, m, w, b, stride, pad, dil, dg, gout):
     return out, [l.grad if l is not None else None for l in leaves]
 
 
-def _compare(args, gout):
+def _compare(args, gout, tol=TOL):
     out, grads = _run_hip(*args, gout)
     oref, gref = _run_oracle(*args, gout)
-    check('out', out, oref, TOL)
+    check('out', out, oref, tol)
     for name, a, r in zip(('grad_input', 'grad_offset', 'grad_mask', 'grad_weight', 'grad_bias'), grads, gref):
         if r is not None:
             check(name, a, r, TOL_G)
 
 
-def test_fixture_dcn_op():
+def test_fixture_dcn_op(gemm_mode):
+    TOL = 2e-5 if gemm_mode == 'f32' else 1e-4
     g = load_golden('dcn_op')
     t = {k: torch.from_numpy(v) for k, v in g.items() if v.ndim > 0}
     out, grads = _run_hip(t['x'], t['offset'], t['mask'], t['weight'], t['bias'], 1, 1, 1, int(g['dg']), t['gout'])
@@ -62,7 +63,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=lambda s: '-'.join(str(v) for v in s))
-def test_random_shapes_vs_oracle(shape):
+def test_random_shapes_vs_oracle(shape, gemm_mode):
     B, C, Co, dg, H, W, stride, pad, dil, ostd, with_bias = shape
     g = torch.Generator().manual_seed(sum(int(v) for v in shape[:9]))
     Ho = (H + 2 * pad - (dil * 2 + 1)) // stride + 1
@@ -73,10 +74,11 @@ def test_random_shapes_vs_oracle(shape):
     w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
     b = torch.randn(Co, generator=g) if with_bias else None
     gout = torch.randn(B, Co, Ho, Wo, generator=g)
-    _compare((x, off, m, w, b, stride, pad, dil, dg), gout)
+    _compare((x, off, m, w, b, stride, pad, dil, dg), gout, 2e-5 if gemm_mode == 'f32' else 1e-4)
 
 
-def test_identities():
+def test_identities(gemm_mode):
+    TOL = 2e-5 if gemm_mode == 'f32' else 1e-4
     import torch.nn.functional as F
     from realvsr_amd.archs.dcn import modulated_deform_conv
     d = dev()
