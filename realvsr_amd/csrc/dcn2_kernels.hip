@@ -211,3 +211,287 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
     if (mt == 2) return launch_dcn_fwd2<8, 2>(p, wp, st);
     return launch_dcn_fwd2<8, 4>(p, wp, st);
 }
+
+// ==========================================================================================
+// Backward w.r.t. input / offsets / mask, second generation.
+//
+//   col_grad[(tap, c), px] = sum_o W[o, (tap, c)] * gOut[o, px]        (matrix cores, bf16x3)
+//   grad_mask / grad_offset = reductions of col_grad * {bilinear(x), d bilinear/d(y,x)} over the group
+//   grad_input             += scatter of col_grad * mask * corner weights
+//
+// The col_grad tile never leaves the accumulator registers: an M tile is ordered
+// (2 taps) x (16 channels of the chunk), so in the D layout lane (px, half) owns, for each tap and
+// octet, exactly channels 4*half .. 4*half+3 -- the same channel quad the x tile stores as one
+// float4 per position.  Each lane therefore consumes its 16 accumulator values with 4 float4 corner
+// fetches per (tap, octet), adds its partial sums to its partner lane's (lane ^ 32) and scatters
+// into an LDS grad_input tile (ds_add_f32) that is flushed with one global atomic per touched cell.
+// gOut (x act') is held as B fragments in registers for the whole tile (it is reused by all M tiles).
+template <int NK>
+__global__ void pack_weights_bwd_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int C, int nchunks) {
+    // packed[chunk][tp (5)][part][ooct (2*NK)][row (32)][8 o];  row -> tap = 2*tp + (row >> 4), c = 16*chunk + (row & 15)
+    const size_t total = (size_t)nchunks * 5 * (2 * NK) * 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx & 31);
+        size_t r = idx >> 5;
+        const int ooct = (int)(r % (2 * NK));
+        r /= (2 * NK);
+        const int tp = (int)(r % 5), chunk = (int)(r / 5);
+        const int tap = 2 * tp + (row >> 4), c = 16 * chunk + (row & 15);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * ooct + j;
+            v[j] = (tap < 9 && c < C && o < Co) ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+        }
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        const size_t blk = ((size_t)chunk * 5 + tp) * 2, per = (size_t)(2 * NK) * 32;
+        packed[blk * per + ooct * 32 + row] = hi;
+        packed[(blk + 1) * per + ooct * 32 + row] = lo;
+    }
+}
+
+struct DcnBwdIn2Params {
+    DcnGeom d;
+    TView g;            // grad_output view (Co, Ho, Wo), optional fused act'
+    float* gx;          // (B, C, H, W), zero on entry
+    float* goff;
+    float* gmask;
+    size_t goff_bs, gmask_bs;
+};
+
+template <int TH, int NK>
+__global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2Params p, const bf16x8* __restrict__ wpack) {
+    constexpr int NT = TH * 64;
+    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    constexpr int WBLK = 2 * (2 * NK) * 32;  // vectors per (chunk, tap-pair) block (hi + lo)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);   // [4 quads][NPOS]   x tile of the chunk
+    float4* gt = xt + 4 * NPOS;                         // [4 quads][NPOS]   grad_input accumulation tile
+    bf16x8* wsb = reinterpret_cast<bf16x8*>(gt + 4 * NPOS);  // [5][WBLK]
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
+    const int x0 = tx * 32, y0 = ty * TH, b = blockIdx.z;
+    const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;
+    const int nchunks = (d.C + 15) / 16;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int oy = y0 + wave, ox = x0 + lo;
+    const bool px_ok = oy < d.Ho && ox < d.Wo;
+    const size_t pix = (size_t)oy * d.Wo + ox;
+
+    // gOut (x act') as B fragments: lane (px, hi) holds o = 8*(2*ks + hi) .. +7 for ks < NK
+    bf16x8 gh[NK], gl[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * (2 * ks + hi) + j;
+            v[j] = (px_ok && o < d.Co) ? tview_get(p.g, b, o, oy, ox) : 0.f;
+        }
+        split8(v, gh[ks], gl[ks]);
+    }
+
+    for (int e = tid; e < 4 * NPOS; e += NT) gt[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * 16;
+        {
+            const bf16x8* src = wpack + (size_t)chunk * 5 * WBLK;
+#pragma unroll 4
+            for (int e = tid; e < 5 * WBLK; e += NT) wsb[e] = src[e];
+        }
+        for (int it = tid; it < 4 * NPOS; it += NT) {
+            const int quad = it / NPOS, pos = it - quad * NPOS;
+            const int r = pos / TC, s = pos - r * TC;
+            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
+                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
+                v.x = src[0];
+                if (cb + 1 < d.C) v.y = src[HW];
+                if (cb + 2 < d.C) v.z = src[2 * HW];
+                if (cb + 3 < d.C) v.w = src[3 * HW];
+            }
+            xt[it] = v;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int tp = 0; tp < 5; ++tp) {
+            f32x16 acc = zero16();
+            const bf16x8* wb_hi = wsb + tp * WBLK;
+            const bf16x8* wb_lo = wb_hi + (2 * NK) * 32;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo], al = wb_lo[(2 * ks + hi) * 32 + lo];
+                acc = mfma_bf16(ah, gh[ks], acc);
+                acc = mfma_bf16(ah, gl[ks], acc);
+                acc = mfma_bf16(al, gh[ks], acc);
+            }
+            // consume: regs 8*tsel + 4*oc + e  <->  tap 2*tp+tsel, octet oc of the chunk, channel 4*hi + e
+#pragma unroll
+            for (int tsel = 0; tsel < 2; ++tsel) {
+                const int tap = 2 * tp + tsel;
+                if (tap >= 9) continue;
+#pragma unroll
+                for (int oc = 0; oc < 2; ++oc) {
+                    const int cb8 = c0 + 8 * oc;
+                    if (cb8 >= d.C) continue;  // uniform
+                    const int g = cb8 / d.cpg;
+                    float gy_s = 0.f, gx_s = 0.f, gm_s = 0.f, m = 0.f;
+                    if (px_ok) {
+                        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * tap) * hw + pix;
+                        const float dy = offp[0], dx = offp[hw];
+                        m = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + tap) * hw + pix];
+                        if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
+                        const float y = (float)(oy * d.stride - d.pad + (tap / 3) * d.dil) + dy;
+                        const float x = (float)(ox * d.stride - d.pad + (tap % 3) * d.dil) + dx;
+                        if (y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W) {
+                            const float fy = floorf(y), fx = floorf(x);
+                            const int yi = (int)fy, xi = (int)fx;
+                            const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+                            const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                            const float w00 = (vy0 && vx0) ? hy * hx : 0.f, w01 = (vy0 && vx1) ? hy * lx : 0.f;
+                            const float w10 = (vy1 && vx0) ? ly * hx : 0.f, w11 = (vy1 && vx1) ? ly * lx : 0.f;
+                            const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1;
+                            const int cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                            const int r0 = cy0 - ty0, r1 = cy1 - ty0, s0 = cx0 - tx0, s1 = cx1 - tx0;
+                            const bool in_tile = r0 >= 0 && r1 < TR && s0 >= 0 && s1 < TC;
+                            const int quad = 2 * oc + hi;
+                            const int cq = cb8 + 4 * hi;  // this lane's first channel
+                            float4 a00, a01, a10, a11;    // corner values of the lane's 4 channels (0 where corner invalid)
+                            if (in_tile) {
+                                const float4* xq = xt + quad * NPOS;
+                                a00 = xq[r0 * TC + s0]; a01 = xq[r0 * TC + s1]; a10 = xq[r1 * TC + s0]; a11 = xq[r1 * TC + s1];
+                            } else {
+                                const float* pl = d.x + ((size_t)b * d.C + cq) * HW;
+                                const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                                float t00[4], t01[4], t10[4], t11[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const bool cok = cq + e < d.C;
+                                    const float* q = pl + (size_t)e * HW;
+                                    t00[e] = cok ? q[i00] : 0.f; t01[e] = cok ? q[i01] : 0.f;
+                                    t10[e] = cok ? q[i10] : 0.f; t11[e] = cok ? q[i11] : 0.f;
+                                }
+                                a00 = make_float4(t00[0], t00[1], t00[2], t00[3]); a01 = make_float4(t01[0], t01[1], t01[2], t01[3]);
+                                a10 = make_float4(t10[0], t10[1], t10[2], t10[3]); a11 = make_float4(t11[0], t11[1], t11[2], t11[3]);
+                            }
+                            const float z00 = (vy0 && vx0) ? 1.f : 0.f, z01 = (vy0 && vx1) ? 1.f : 0.f;
+                            const float z10 = (vy1 && vx0) ? 1.f : 0.f, z11 = (vy1 && vx1) ? 1.f : 0.f;
+                            const float c00[4] = {a00.x * z00, a00.y * z00, a00.z * z00, a00.w * z00};
+                            const float c01[4] = {a01.x * z01, a01.y * z01, a01.z * z01, a01.w * z01};
+                            const float c10[4] = {a10.x * z10, a10.y * z10, a10.z * z10, a10.w * z10};
+                            const float c11[4] = {a11.x * z11, a11.y * z11, a11.z * z11, a11.w * z11};
+                            float t[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float cgv = acc[8 * tsel + 4 * oc + e];
+                                gm_s += cgv * (w00 * c00[e] + w01 * c01[e] + w10 * c10[e] + w11 * c11[e]);
+                                t[e] = cgv * m;
+                                gy_s += (hx * (c10[e] - c00[e]) + lx * (c11[e] - c01[e])) * t[e];
+                                gx_s += (hy * (c01[e] - c00[e]) + ly * (c11[e] - c10[e])) * t[e];
+                            }
+                            if (in_tile) {
+                                float* gq = reinterpret_cast<float*>(gt + quad * NPOS);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (w00 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r0 * TC + s0) + e, w00 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (w01 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r0 * TC + s1) + e, w01 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (w10 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r1 * TC + s0) + e, w10 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (w11 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r1 * TC + s1) + e, w11 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            } else {
+                                float* gp = p.gx + ((size_t)b * d.C + cq) * HW;
+                                const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (cq + e >= d.C) continue;
+                                    float* q = gp + (size_t)e * HW;
+                                    if (w00 != 0.f) atomicAdd(q + i00, w00 * t[e]);
+                                    if (w01 != 0.f) atomicAdd(q + i01, w01 * t[e]);
+                                    if (w10 != 0.f) atomicAdd(q + i10, w10 * t[e]);
+                                    if (w11 != 0.f) atomicAdd(q + i11, w11 * t[e]);
+                                }
+                            }
+                        }
+                    }
+                    // add the partner lane's half of the octet (channels 4*(1-hi) ..)
+                    gy_s += __shfl_xor(gy_s, 32);
+                    gx_s += __shfl_xor(gx_s, 32);
+                    gm_s += __shfl_xor(gm_s, 32);
+                    if (px_ok && hi == 0) {
+                        if (d.mask_logit) gm_s *= m * (1.f - m);
+                        float* go = p.goff + (size_t)b * p.goff_bs + (size_t)(g * 18 + 2 * tap) * hw + pix;
+                        float* gk = p.gmask + (size_t)b * p.gmask_bs + (size_t)(g * 9 + tap) * hw + pix;
+                        if (cb8 % d.cpg == 0) {  // first octet of this deformable group: overwrite
+                            go[0] = gy_s;
+                            go[hw] = gx_s;
+                            gk[0] = gm_s;
+                        } else {                 // group wider than 8 channels: accumulate
+                            go[0] += gy_s;
+                            go[hw] += gx_s;
+                            gk[0] += gm_s;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush the accumulation tile: one global atomic per touched cell
+        for (int it = tid; it < 4 * NPOS; it += NT) {
+            const float4 v = gt[it];
+            if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
+                gt[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int quad = it / NPOS, pos = it - quad * NPOS;
+                const int yy = ty0 + pos / TC, xx = tx0 + pos % TC, cb = c0 + 4 * quad;
+                if (yy >= 0 && yy < d.H && xx >= 0 && xx < d.W) {
+                    float* q = p.gx + ((size_t)b * d.C + cb) * HW + (size_t)yy * d.W + xx;
+                    if (cb < d.C && v.x != 0.f) atomicAdd(q, v.x);
+                    if (cb + 1 < d.C && v.y != 0.f) atomicAdd(q + HW, v.y);
+                    if (cb + 2 < d.C && v.z != 0.f) atomicAdd(q + 2 * HW, v.z);
+                    if (cb + 3 < d.C && v.w != 0.f) atomicAdd(q + 3 * HW, v.w);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C) {
+    const int nk = Co <= 16 ? 1 : (Co <= 32 ? 2 : (Co <= 64 ? 4 : 8));
+    return (size_t)((C + 15) / 16) * 5 * 2 * (2 * nk) * 32 * 16;
+}
+
+template <int NK>
+static int launch_bwdin2(const DcnBwdIn2Params& p, const float* weight, void* workspace, hipStream_t st) {
+    constexpr int TH = 8;
+    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    const DcnGeom& d = p.d;
+    const int nchunks = (d.C + 15) / 16;
+    const size_t total = (size_t)nchunks * 5 * (2 * NK) * 32;
+    hipLaunchKernelGGL(pack_weights_bwd_kernel<NK>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight,
+                       (bf16x8*)workspace, d.Co, d.C, nchunks);
+    const size_t lds = (size_t)16 * (8 * TR * TC + 5 * 2 * (2 * NK) * 32);
+    auto k = dcn_bwdin2_kernel<TH, NK>;
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin2: cannot reserve %zu B of LDS", lds);
+    dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), 1, d.B);
+    hipLaunchKernelGGL(k, grid, dim3(TH * 64), lds, st, p, (const bf16x8*)workspace);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin2 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (d.cpg % 8 != 0 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < rvsr_dcn_bwdin2_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
+    DcnBwdIn2Params p;
+    p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
+    if (d.Co <= 16) return launch_bwdin2<1>(p, weight, workspace, st);
+    if (d.Co <= 32) return launch_bwdin2<2>(p, weight, workspace, st);
+    if (d.Co <= 64) return launch_bwdin2<4>(p, weight, workspace, st);
+    return launch_bwdin2<8>(p, weight, workspace, st);
+}

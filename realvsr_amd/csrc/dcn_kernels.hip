@@ -427,7 +427,9 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     const int ntiles = batch * ((Ho + 3) / 4) * ((Wo + 31) / 32);
     const int gy = (channels_out + 63) / 64, gz = (channels + DCN_CC - 1) / DCN_CC;
     const size_t Q = 4 * (size_t)bww_P(ntiles, gy, gz);
-    return sizeof(float) * Q * ((size_t)channels_out * channels * 9 + channels_out);
+    const size_t a = sizeof(float) * Q * ((size_t)channels_out * channels * 9 + channels_out);
+    const size_t b2 = rvsr_dcn_bwdin2_workspace_bytes(channels_out, channels);
+    return a > b2 ? a : b2;
 }
 
 static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout, const float* gact, float gact_slope,
@@ -440,12 +442,18 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     const int nty = (d.Ho + 3) / 4;
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
+        int rc2 = RVSR_ERR_UNSUPPORTED;
+        if (rvsr_g_gemm_mode == 0)
+            rc2 = rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
+        if (rc2 != RVSR_ERR_UNSUPPORTED && rc2 != RVSR_OK) return rc2;
         DcnBwdInParams p;
         p.d = d; p.w = weight; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
         const int CoP = (d.Co + 1) & ~1;
         const size_t lds = sizeof(float) * ((size_t)CoP * DCN_NPX + (size_t)CoP * DCN_KC + DCN_KC * DCN_NPX + DCN_CC * 14 * 42);
         if (lds > 160 * 1024) FAIL(RVSR_ERR_UNSUPPORTED, "dcn backward: channels_out %d needs %zu B of LDS", d.Co, lds);
-        if (d.cpg % DCN_CC == 0) {
+        if (rc2 == RVSR_OK) {
+            // done by the second-generation kernel
+        } else if (d.cpg % DCN_CC == 0) {
             if (set_lds(dcn_bwd_input_kernel<8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
             hipLaunchKernelGGL(dcn_bwd_input_kernel<8>, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);
         } else {
