@@ -267,8 +267,10 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
     constexpr int WBLK = 2 * (2 * NK) * 32;  // vectors per (chunk, tap-pair) block (hi + lo)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);   // [4 quads][NPOS]   x tile of the chunk
-    float4* gt = xt + 4 * NPOS;                         // [4 quads][NPOS]   grad_input accumulation tile
-    bf16x8* wsb = reinterpret_cast<bf16x8*>(gt + 4 * NPOS);  // [5][WBLK]
+    // grad_input accumulation tile, channel-PLANAR [16 ch][NPOS] so that the ds_add_f32 of consecutive pixels
+    // hit consecutive banks (a float4-per-position layout is a 4-way conflict on every atomic)
+    float* gt = reinterpret_cast<float*>(xt + 4 * NPOS);
+    bf16x8* wsb = reinterpret_cast<bf16x8*>(gt + 16 * NPOS);  // [5][WBLK]
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
         split8(v, gh[ks], gl[ks]);
     }
 
-    for (int e = tid; e < 4 * NPOS; e += NT) gt[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < 16 * NPOS; e += NT) gt[e] = 0.f;
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * 16;
@@ -395,13 +397,13 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
                                 gx_s += (hy * (c01[e] - c00[e]) + ly * (c11[e] - c10[e])) * t[e];
                             }
                             if (in_tile) {
-                                float* gq = reinterpret_cast<float*>(gt + quad * NPOS);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    if (w00 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r0 * TC + s0) + e, w00 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (w01 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r0 * TC + s1) + e, w01 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (w10 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r1 * TC + s0) + e, w10 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (w11 != 0.f) __hip_atomic_fetch_add(gq + 4 * (r1 * TC + s1) + e, w11 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    float* gq = gt + (4 * quad + e) * NPOS;
+                                    if (w00 != 0.f) __hip_atomic_fetch_add(gq + r0 * TC + s0, w00 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (w01 != 0.f) __hip_atomic_fetch_add(gq + r0 * TC + s1, w01 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (w10 != 0.f) __hip_atomic_fetch_add(gq + r1 * TC + s0, w10 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (w11 != 0.f) __hip_atomic_fetch_add(gq + r1 * TC + s1, w11 * t[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 }
                             } else {
                                 float* gp = p.gx + ((size_t)b * d.C + cq) * HW;
@@ -440,20 +442,15 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
             }
         }
         __syncthreads();
-        // flush the accumulation tile: one global atomic per touched cell
-        for (int it = tid; it < 4 * NPOS; it += NT) {
-            const float4 v = gt[it];
-            if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
-                gt[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int quad = it / NPOS, pos = it - quad * NPOS;
-                const int yy = ty0 + pos / TC, xx = tx0 + pos % TC, cb = c0 + 4 * quad;
-                if (yy >= 0 && yy < d.H && xx >= 0 && xx < d.W) {
-                    float* q = p.gx + ((size_t)b * d.C + cb) * HW + (size_t)yy * d.W + xx;
-                    if (cb < d.C && v.x != 0.f) atomicAdd(q, v.x);
-                    if (cb + 1 < d.C && v.y != 0.f) atomicAdd(q + HW, v.y);
-                    if (cb + 2 < d.C && v.z != 0.f) atomicAdd(q + 2 * HW, v.z);
-                    if (cb + 3 < d.C && v.w != 0.f) atomicAdd(q + 3 * HW, v.w);
-                }
+        // flush the accumulation tile: one global atomic per touched cell (coalesced along W)
+        for (int it = tid; it < 16 * NPOS; it += NT) {
+            const float v = gt[it];
+            if (v != 0.f) {
+                gt[it] = 0.f;
+                const int cc = it / NPOS, pos = it - cc * NPOS;
+                const int yy = ty0 + pos / TC, xx = tx0 + pos % TC, c = c0 + cc;
+                if (c < d.C && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W)
+                    atomicAdd(p.gx + ((size_t)b * d.C + c) * HW + (size_t)yy * d.W + xx, v);
             }
         }
         __syncthreads();
@@ -494,4 +491,169 @@ int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g
     if (d.Co <= 32) return launch_bwdin2<2>(p, weight, workspace, st);
     if (d.Co <= 64) return launch_bwdin2<4>(p, weight, workspace, st);
     return launch_bwdin2<8>(p, weight, workspace, st);
+}
+
+// ==========================================================================================
+// Backward w.r.t. weight / bias, second generation: same GEMM as dcn_bwd_weight_kernel
+// (gW[o, k] += sum_px gOut[o, px] * col[k, px], exact-f32 MFMA, deterministic partials) but the column
+// tile is built from an LDS x tile (no dependent global gathers) by 8 waves instead of 4.
+struct DcnBwdW2Params {
+    DcnGeom d;
+    TView g;
+    float* part;   // [8P][Co][C][9]
+    float* bpart;  // [8P][Co] or nullptr
+    int P, nty;
+};
+
+__global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params p) {
+    constexpr int GP = 65, CP = 97, NT = 512;
+    constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);       // [2 quads][NPOS]
+    float* gT = reinterpret_cast<float*>(xt + 2 * NPOS);    // [128][65]
+    float* colT = gT + DCN_NPX * GP;                        // [128][97]; col 72 = 1 (bias), 73.. = 0
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int mb = blockIdx.y, c0 = blockIdx.z * 8;
+    const bool m1_live = mb * 64 + 32 < d.Co;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int g = c0 / d.cpg;
+
+    for (int e = tid; e < DCN_NPX * (CP - DCN_KC); e += NT) {
+        const int px = e / (CP - DCN_KC), j = e - px * (CP - DCN_KC);
+        colT[px * CP + DCN_KC + j] = j == 0 ? 1.f : 0.f;
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = zero16();
+
+    const int ntiles = d.B * p.nty * d.ntx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.P) {
+        const int b = tile / (p.nty * d.ntx);
+        const int trem = tile - b * (p.nty * d.ntx);
+        const int ty = trem / d.ntx, tx = trem - ty * d.ntx;
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;
+#pragma unroll 2
+        for (int e = tid; e < 64 * DCN_NPX; e += NT) {
+            const int ol = e >> 7, px = e & 127;
+            const int o = mb * 64 + ol;
+            gT[px * GP + ol] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
+        }
+        for (int it = tid; it < 2 * NPOS; it += NT) {
+            const int quad = it / NPOS, pos = it - quad * NPOS;
+            const int r = pos / TC, s = pos - r * TC;
+            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
+                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
+                v.x = src[0];
+                if (cb + 1 < d.C) v.y = src[HW];
+                if (cb + 2 < d.C) v.z = src[2 * HW];
+                if (cb + 3 < d.C) v.w = src[3 * HW];
+            }
+            xt[it] = v;
+        }
+        __syncthreads();
+        // column tile: item = (pixel, tap); 8 channels of the chunk share the sampling geometry
+        for (int it = tid; it < DCN_NPX * 9; it += NT) {
+            const int px = it & 127, tap = it >> 7;
+            const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (oy < d.Ho && ox < d.Wo) {
+                const size_t pix = (size_t)oy * d.Wo + ox;
+                const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * tap) * hw + pix;
+                const float dy = offp[0], dx = offp[hw];
+                float m = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + tap) * hw + pix];
+                if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
+                const float y = (float)(oy * d.stride - d.pad + (tap / 3) * d.dil) + dy;
+                const float x = (float)(ox * d.stride - d.pad + (tap % 3) * d.dil) + dx;
+                if (y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W) {
+                    const float fy = floorf(y), fx = floorf(x);
+                    const int yi = (int)fy, xi = (int)fx;
+                    const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+                    const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                    const float w00 = (vy0 && vx0) ? hy * hx : 0.f, w01 = (vy0 && vx1) ? hy * lx : 0.f;
+                    const float w10 = (vy1 && vx0) ? ly * hx : 0.f, w11 = (vy1 && vx1) ? ly * lx : 0.f;
+                    const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1;
+                    const int cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                    const int r0 = cy0 - ty0, r1 = cy1 - ty0, s0 = cx0 - tx0, s1 = cx1 - tx0;
+                    if (r0 >= 0 && r1 < TR && s0 >= 0 && s1 < TC) {
+                        const int p00 = r0 * TC + s0, p01 = r0 * TC + s1, p10 = r1 * TC + s0, p11 = r1 * TC + s1;
+                        const float4 a00 = xt[p00], b00 = xt[NPOS + p00], a01 = xt[p01], b01 = xt[NPOS + p01];
+                        const float4 a10 = xt[p10], b10 = xt[NPOS + p10], a11 = xt[p11], b11 = xt[NPOS + p11];
+                        v[0] = w00 * a00.x + w01 * a01.x + w10 * a10.x + w11 * a11.x;
+                        v[1] = w00 * a00.y + w01 * a01.y + w10 * a10.y + w11 * a11.y;
+                        v[2] = w00 * a00.z + w01 * a01.z + w10 * a10.z + w11 * a11.z;
+                        v[3] = w00 * a00.w + w01 * a01.w + w10 * a10.w + w11 * a11.w;
+                        v[4] = w00 * b00.x + w01 * b01.x + w10 * b10.x + w11 * b11.x;
+                        v[5] = w00 * b00.y + w01 * b01.y + w10 * b10.y + w11 * b11.y;
+                        v[6] = w00 * b00.z + w01 * b01.z + w10 * b10.z + w11 * b11.z;
+                        v[7] = w00 * b00.w + w01 * b01.w + w10 * b10.w + w11 * b11.w;
+                    } else {
+                        const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                        const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (c0 + j < d.C) {
+                                const float* q = pl + (size_t)j * HW;
+                                v[j] = w00 * q[i00] + w01 * q[i01] + w10 * q[i10] + w11 * q[i11];
+                            }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= m;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) colT[px * CP + j * 9 + tap] = v[j];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {  // wave w: pixels 16w .. 16w+15
+            const int px = wave * 16 + 2 * ks + hi;
+            const float a0 = gT[px * GP + lo], a1 = gT[px * GP + 32 + lo];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const float bv = colT[px * CP + n * 32 + lo];
+                acc[0][n] = mfma32(a0, bv, acc[0][n]);
+                if (m1_live) acc[1][n] = mfma32(a1, bv, acc[1][n]);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int q = blockIdx.x * 8 + wave;
+    const int K = d.C * 9;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int kr = n * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mb * 64 + m * 32 + drow(r, hi);
+                if (o >= d.Co) continue;
+                const int kg = c0 * 9 + kr;
+                if (kr < DCN_KC && kg < K) p.part[((size_t)q * d.Co + o) * K + kg] = acc[m][n][r];
+                if (kr == DCN_KC && p.bpart != nullptr && blockIdx.z == 0) p.bpart[(size_t)q * d.Co + o] = acc[m][n][r];
+            }
+        }
+    }
+}
+
+// returns the number of partials written (8 * P), or -1 if the geometry is not covered
+int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* bpart_or_null, int P, int nty, int gy, int gz,
+                          hipStream_t st) {
+    if (d.cpg % 8 != 0) return -1;
+    DcnBwdW2Params p;
+    p.d = d; p.g = g; p.part = part; p.bpart = bpart_or_null; p.P = P; p.nty = nty;
+    constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    const size_t lds = (size_t)16 * 2 * TR * TC + sizeof(float) * (DCN_NPX * 65 + DCN_NPX * 97);
+    if (set_lds(dcn_bwdw2_kernel, lds)) return -2;
+    hipLaunchKernelGGL(dcn_bwdw2_kernel, dim3(P, gy, gz), dim3(512), lds, st, p);
+    return 8 * P;
 }

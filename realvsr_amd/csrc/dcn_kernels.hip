@@ -426,7 +426,7 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     const int Ho = (height + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * 2 + 1)) / stride + 1;
     const int ntiles = batch * ((Ho + 3) / 4) * ((Wo + 31) / 32);
     const int gy = (channels_out + 63) / 64, gz = (channels + DCN_CC - 1) / DCN_CC;
-    const size_t Q = 4 * (size_t)bww_P(ntiles, gy, gz);
+    const size_t Q = 8 * (size_t)bww_P(ntiles, gy, gz);
     const size_t a = sizeof(float) * Q * ((size_t)channels_out * channels * 9 + channels_out);
     const size_t b2 = rvsr_dcn_bwdin2_workspace_bytes(channels_out, channels);
     return a > b2 ? a : b2;
@@ -466,14 +466,22 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         p.d = d; p.g = g; p.nty = nty;
         const int gy = (d.Co + 63) / 64, gz = (d.C + DCN_CC - 1) / DCN_CC;
         p.P = bww_P(d.B * nty * d.ntx, gy, gz);
-        const size_t Q = 4 * (size_t)p.P, nw = (size_t)d.Co * d.C * 9;
+        size_t Q = 4 * (size_t)p.P;
+        const size_t nw = (size_t)d.Co * d.C * 9;
         p.part = (float*)workspace;
-        p.bpart = gb ? p.part + Q * nw : nullptr;
-        const size_t lds = sizeof(float) * (DCN_NPX * 65 + DCN_NPX * 97);
-        if (d.cpg % DCN_CC == 0) {
-            if (set_lds(dcn_bwd_weight_kernel<8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_weight: cannot reserve %zu B of LDS", lds);
-            hipLaunchKernelGGL(dcn_bwd_weight_kernel<8>, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
-        } else {
+        int q2 = -1;
+        if (d.cpg % DCN_CC == 0) {  // second-generation builder (LDS x tile, 8 waves): 8P partials
+            float* bp2 = gb ? p.part + (size_t)8 * p.P * nw : nullptr;
+            q2 = rvsr_launch_dcn_bwdw2(d, g, p.part, bp2, p.P, nty, gy, gz, st);
+            if (q2 == -2) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdw2: cannot reserve LDS");
+            if (q2 > 0) {
+                Q = (size_t)q2;
+                p.bpart = bp2;
+            }
+        }
+        if (q2 <= 0) {
+            p.bpart = gb ? p.part + Q * nw : nullptr;
+            const size_t lds = sizeof(float) * (DCN_NPX * 65 + DCN_NPX * 97);
             if (set_lds(dcn_bwd_weight_kernel<0>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_weight: cannot reserve %zu B of LDS", lds);
             hipLaunchKernelGGL(dcn_bwd_weight_kernel<0>, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
         }
