@@ -657,3 +657,311 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
     hipLaunchKernelGGL(dcn_bwdw2_kernel, dim3(P, gy, gz), dim3(512), lds, st, p);
     return 8 * P;
 }
+
+// ==========================================================================================
+// Backward w.r.t. input / offsets / mask, third generation: no floating-point atomics on the
+// scatter.  MI355X measurements that drove this (profiles/r01_notes.md): ds_add_f32 costs ~117
+// LDS cycles per wave-instruction (LDS_IDX_ACTIVE 58x the forward kernel's), global
+// atomicAdd(float) tops out near 70 G atomics/s -- 2304 of them per pixel is the whole budget.
+//
+//   * K chunk = 8 channels (one k-octet); M tile = 4 taps x 8 channels, so in the D layout lane
+//     (px, half) owns channels 4*half..4*half+3 of 4 taps = one float4 per corner.
+//   * every wave scatters into its OWN private window of the grad_input tile (rows oy-1-R ..
+//     oy+2+R), so waves never touch the same LDS cell;
+//   * inside a wave, lanes that hit the same cell in the same instruction are serialised by a
+//     claim / read-back round (write lane id, read it back, winners do a plain float4
+//     read-modify-write, losers retry) -- one round in the common collision-free case;
+//   * after a chunk, owner threads sum the <= 8 overlapping private windows per cell and issue one
+//     global atomic per touched cell (different workgroups' halos overlap).
+// Geometry: stride 1, dilation 1 (what EDVR/TDAN use); anything else takes the v2 kernel.
+#define D3_R 2
+#define D3_PR (2 * D3_R + 4)        // private window rows
+#define D3_TC 40                    // tile columns: x0-pad-R .. (32 + 2R + 3 = 39 needed)
+#define D3_TH 8
+
+template <int NK>
+__global__ void pack_weights_bwd3_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int C, int nchunks) {
+    // packed[chunk][mt (3)][part][ooct (2*NK)][row (32)][8 o];  row -> tap = 4*mt + (row >> 3), c = 8*chunk + (row & 7)
+    const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx & 31);
+        size_t r = idx >> 5;
+        const int ooct = (int)(r % (2 * NK));
+        r /= (2 * NK);
+        const int mt = (int)(r % 3), chunk = (int)(r / 3);
+        const int tap = 4 * mt + (row >> 3), c = 8 * chunk + (row & 7);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * ooct + j;
+            v[j] = (tap < 9 && c < C && o < Co) ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+        }
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        const size_t blk = ((size_t)chunk * 3 + mt) * 2, per = (size_t)(2 * NK) * 32;
+        packed[blk * per + ooct * 32 + row] = hi;
+        packed[(blk + 1) * per + ooct * 32 + row] = lo;
+    }
+}
+
+// add `c` to priv[idx] (float4) with intra-wave collision handling; `pend` = this lane has work
+__device__ __forceinline__ void claim_add(volatile int* claim, volatile float* priv, int idx, float4 c, bool pend, int lane) {
+    while (__any(pend)) {
+        if (pend) claim[idx] = lane;
+        asm volatile("" ::: "memory");
+        const bool win = pend && claim[idx] == lane;
+        if (win) {
+            volatile float* q = priv + 4 * idx;
+            const float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+            q[0] = a0 + c.x;
+            q[1] = a1 + c.y;
+            q[2] = a2 + c.z;
+            q[3] = a3 + c.w;
+            pend = false;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdIn2Params p, const bf16x8* __restrict__ wpack) {
+    constexpr int NT = D3_TH * 64, TC = D3_TC, PR = D3_PR;
+    constexpr int TR = D3_TH + PR - 1;             // shared rows: y0-pad-R .. (union of the private windows)
+    constexpr int NPOS = TR * TC, PPOS = PR * TC;  // positions of the shared x tile / of one private window
+    constexpr int WBLK = 2 * (2 * NK) * 32;        // vectors per (chunk, M tile) weight block (hi + lo)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);              // [2 quads][NPOS]
+    float4* priv = xt + 2 * NPOS;                                  // [8 waves][2 quads][PPOS]
+    int* claim = reinterpret_cast<int*>(priv + D3_TH * 2 * PPOS);  // [8 waves][2 quads][PPOS]
+    bf16x8* wsb = reinterpret_cast<bf16x8*>(claim + D3_TH * 2 * PPOS);  // [3][WBLK]
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
+    const int x0 = tx * 32, y0 = ty * D3_TH, b = blockIdx.z;
+    const int ty0 = y0 - d.pad - D3_R, tx0 = x0 - d.pad - D3_R;  // stride 1
+    const int nchunks = (d.C + 7) / 8;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int oy = y0 + wave, ox = x0 + lo;
+    const bool px_ok = oy < d.Ho && ox < d.Wo;
+    const size_t pix = (size_t)oy * d.Wo + ox;
+    const float4* xq = xt + hi * NPOS;                       // this lane's channel quad in the shared x tile
+    volatile float* myp = reinterpret_cast<volatile float*>(priv + (wave * 2 + hi) * PPOS);
+    volatile int* myc = claim + (wave * 2 + hi) * PPOS;
+
+    bf16x8 gh[NK], gl[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * (2 * ks + hi) + j;
+            v[j] = (px_ok && o < d.Co) ? tview_get(p.g, b, o, oy, ox) : 0.f;
+        }
+        split8(v, gh[ks], gl[ks]);
+    }
+    for (int e = tid; e < D3_TH * 2 * PPOS; e += NT) priv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * 8;
+        const int g = c0 / d.cpg;
+        {
+            const bf16x8* src = wpack + (size_t)chunk * 3 * WBLK;
+#pragma unroll 3
+            for (int e = tid; e < 3 * WBLK; e += NT) wsb[e] = src[e];
+        }
+        for (int it = tid; it < 2 * NPOS; it += NT) {
+            const int quad = it / NPOS, pos = it - quad * NPOS;
+            const int r = pos / TC, s = pos - r * TC;
+            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
+                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
+                v.x = src[0];
+                if (cb + 1 < d.C) v.y = src[HW];
+                if (cb + 2 < d.C) v.z = src[2 * HW];
+                if (cb + 3 < d.C) v.w = src[3 * HW];
+            }
+            xt[it] = v;
+        }
+        __syncthreads();
+
+        const int cq = c0 + 4 * hi;  // this lane's first channel
+        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pix;
+        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pix;
+#pragma unroll 1
+        for (int mt = 0; mt < 3; ++mt) {
+            f32x16 acc = zero16();
+            const bf16x8* wb_hi = wsb + mt * WBLK;
+            const bf16x8* wb_lo = wb_hi + (2 * NK) * 32;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo], al = wb_lo[(2 * ks + hi) * 32 + lo];
+                acc = mfma_bf16(ah, gh[ks], acc);
+                acc = mfma_bf16(ah, gl[ks], acc);
+                acc = mfma_bf16(al, gh[ks], acc);
+            }
+#pragma unroll
+            for (int tsel = 0; tsel < 4; ++tsel) {
+                const int tap = 4 * mt + tsel;
+                if (tap >= 9) continue;  // uniform
+                float gy_s = 0.f, gx_s = 0.f, gm_s = 0.f, m = 0.f;
+                bool inside = false, in_win = false;
+                float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+                int r0 = 0, r1 = 0, s0 = 0, s1 = 0, cy0 = 0, cy1 = 0, cx0 = 0, cx1 = 0;
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+                if (px_ok) {
+                    const float dy = offp[(size_t)(2 * tap) * hw], dx = offp[(size_t)(2 * tap + 1) * hw];
+                    m = mskp[(size_t)tap * hw];
+                    if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
+                    const float y = (float)(oy - d.pad + tap / 3) + dy;
+                    const float x = (float)(ox - d.pad + tap % 3) + dx;
+                    inside = y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W;
+                    if (inside) {
+                        const float fy = floorf(y), fx = floorf(x);
+                        const int yi = (int)fy, xi = (int)fx;
+                        const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+                        const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                        w00 = (vy0 && vx0) ? hy * hx : 0.f; w01 = (vy0 && vx1) ? hy * lx : 0.f;
+                        w10 = (vy1 && vx0) ? ly * hx : 0.f; w11 = (vy1 && vx1) ? ly * lx : 0.f;
+                        cy0 = vy0 ? yi : 0; cy1 = vy1 ? yi + 1 : d.H - 1;
+                        cx0 = vx0 ? xi : 0; cx1 = vx1 ? xi + 1 : d.W - 1;
+                        r0 = cy0 - ty0; r1 = cy1 - ty0; s0 = cx0 - tx0; s1 = cx1 - tx0;  // shared-tile coords
+                        // this wave's private window = shared rows wave .. wave+PR-1
+                        in_win = r0 >= wave && r1 < wave + PR && s0 >= 0 && s1 < TC;
+                        float4 a00, a01, a10, a11;
+                        if (in_win) {
+                            a00 = xq[r0 * TC + s0]; a01 = xq[r0 * TC + s1]; a10 = xq[r1 * TC + s0]; a11 = xq[r1 * TC + s1];
+                        } else {
+                            const float* pl = d.x + ((size_t)b * d.C + cq) * HW;
+                            const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                            float u00[4], u01[4], u10[4], u11[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool cok = cq + e < d.C;
+                                const float* q = pl + (size_t)e * HW;
+                                u00[e] = cok ? q[i00] : 0.f; u01[e] = cok ? q[i01] : 0.f;
+                                u10[e] = cok ? q[i10] : 0.f; u11[e] = cok ? q[i11] : 0.f;
+                            }
+                            a00 = make_float4(u00[0], u00[1], u00[2], u00[3]); a01 = make_float4(u01[0], u01[1], u01[2], u01[3]);
+                            a10 = make_float4(u10[0], u10[1], u10[2], u10[3]); a11 = make_float4(u11[0], u11[1], u11[2], u11[3]);
+                        }
+                        const float z00 = (vy0 && vx0) ? 1.f : 0.f, z01 = (vy0 && vx1) ? 1.f : 0.f;
+                        const float z10 = (vy1 && vx0) ? 1.f : 0.f, z11 = (vy1 && vx1) ? 1.f : 0.f;
+                        const float c00[4] = {a00.x * z00, a00.y * z00, a00.z * z00, a00.w * z00};
+                        const float c01[4] = {a01.x * z01, a01.y * z01, a01.z * z01, a01.w * z01};
+                        const float c10[4] = {a10.x * z10, a10.y * z10, a10.z * z10, a10.w * z10};
+                        const float c11[4] = {a11.x * z11, a11.y * z11, a11.z * z11, a11.w * z11};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float cgv = acc[4 * tsel + e];
+                            gm_s += cgv * (w00 * c00[e] + w01 * c01[e] + w10 * c10[e] + w11 * c11[e]);
+                            t[e] = cgv * m;
+                            gy_s += (hx * (c10[e] - c00[e]) + lx * (c11[e] - c01[e])) * t[e];
+                            gx_s += (hy * (c01[e] - c00[e]) + ly * (c11[e] - c10[e])) * t[e];
+                        }
+                    }
+                }
+                // ---- scatter (all lanes take part in the claim rounds; `pend` carries the per-lane predicate)
+                {
+                    const int pr0 = r0 - wave, pr1 = r1 - wave;
+                    const bool go = inside && in_win;
+                    claim_add(myc, myp, pr0 * TC + s0, make_float4(w00 * t[0], w00 * t[1], w00 * t[2], w00 * t[3]), go && w00 != 0.f, lane);
+                    claim_add(myc, myp, pr0 * TC + s1, make_float4(w01 * t[0], w01 * t[1], w01 * t[2], w01 * t[3]), go && w01 != 0.f, lane);
+                    claim_add(myc, myp, pr1 * TC + s0, make_float4(w10 * t[0], w10 * t[1], w10 * t[2], w10 * t[3]), go && w10 != 0.f, lane);
+                    claim_add(myc, myp, pr1 * TC + s1, make_float4(w11 * t[0], w11 * t[1], w11 * t[2], w11 * t[3]), go && w11 != 0.f, lane);
+                    if (inside && !in_win) {  // large offset: straight to global memory
+                        float* gp = p.gx + ((size_t)b * d.C + cq) * HW;
+                        const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (cq + e >= d.C) continue;
+                            float* q = gp + (size_t)e * HW;
+                            if (w00 != 0.f) atomicAdd(q + i00, w00 * t[e]);
+                            if (w01 != 0.f) atomicAdd(q + i01, w01 * t[e]);
+                            if (w10 != 0.f) atomicAdd(q + i10, w10 * t[e]);
+                            if (w11 != 0.f) atomicAdd(q + i11, w11 * t[e]);
+                        }
+                    }
+                }
+                gy_s += __shfl_xor(gy_s, 32);
+                gx_s += __shfl_xor(gx_s, 32);
+                gm_s += __shfl_xor(gm_s, 32);
+                if (px_ok && hi == 0) {
+                    if (d.mask_logit) gm_s *= m * (1.f - m);
+                    float* go_ = p.goff + (size_t)b * p.goff_bs + (size_t)(g * 18 + 2 * tap) * hw + pix;
+                    float* gk = p.gmask + (size_t)b * p.gmask_bs + (size_t)(g * 9 + tap) * hw + pix;
+                    if (c0 % d.cpg == 0) {
+                        go_[0] = gy_s;
+                        go_[hw] = gx_s;
+                        gk[0] = gm_s;
+                    } else {
+                        go_[0] += gy_s;
+                        go_[hw] += gx_s;
+                        gk[0] += gm_s;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- merge the private windows: owner thread per (quad, shared row, col)
+        for (int it = tid; it < 2 * NPOS; it += NT) {
+            const int quad = it / NPOS, pos = it - quad * NPOS;
+            const int r = pos / TC, s = pos - r * TC;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int w_lo = r - (PR - 1) > 0 ? r - (PR - 1) : 0, w_hi = r < D3_TH - 1 ? r : D3_TH - 1;
+            for (int w = w_lo; w <= w_hi; ++w) {
+                float4* cell = priv + (w * 2 + quad) * PPOS + (r - w) * TC + s;
+                const float4 v = *cell;
+                if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    *cell = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            const int yy = ty0 + r, xx = tx0 + s, cb = c0 + 4 * quad;
+            if (yy >= 0 && yy < d.H && xx >= 0 && xx < d.W) {
+                float* q = p.gx + ((size_t)b * d.C + cb) * HW + (size_t)yy * d.W + xx;
+                if (cb < d.C && sum.x != 0.f) atomicAdd(q, sum.x);
+                if (cb + 1 < d.C && sum.y != 0.f) atomicAdd(q + HW, sum.y);
+                if (cb + 2 < d.C && sum.z != 0.f) atomicAdd(q + 2 * HW, sum.z);
+                if (cb + 3 < d.C && sum.w != 0.f) atomicAdd(q + 3 * HW, sum.w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int nk_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : (Co <= 64 ? 4 : 8)); }
+size_t rvsr_dcn_bwdin3_workspace_bytes(int Co, int C) { return (size_t)((C + 7) / 8) * 3 * 2 * (2 * nk_of(Co)) * 32 * 16; }
+
+template <int NK>
+static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* workspace, hipStream_t st) {
+    const DcnGeom& d = p.d;
+    const int nchunks = (d.C + 7) / 8;
+    const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
+    hipLaunchKernelGGL(pack_weights_bwd3_kernel<NK>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight,
+                       (bf16x8*)workspace, d.Co, d.C, nchunks);
+    constexpr int TR = D3_TH + D3_PR - 1, PPOS = D3_PR * D3_TC;
+    const size_t lds = (size_t)16 * (2 * TR * D3_TC + D3_TH * 2 * PPOS + 3 * 2 * (2 * NK) * 32) + (size_t)4 * D3_TH * 2 * PPOS;
+    auto k = dcn_bwdin3_kernel<NK>;
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin3: cannot reserve %zu B of LDS", lds);
+    dim3 grid(d.ntx * ((d.Ho + D3_TH - 1) / D3_TH), 1, d.B);
+    hipLaunchKernelGGL(k, grid, dim3(D3_TH * 64), lds, st, p, (const bf16x8*)workspace);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin3 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    // Co > 64 would need a 49 KB weight block on top of the private windows: exceeds 160 KB of LDS -> v2 kernel
+    if (d.cpg % 8 != 0 || d.Co > 64 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < rvsr_dcn_bwdin3_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
+    DcnBwdIn2Params p;
+    p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
+    switch (nk_of(d.Co)) {
+        case 1: return launch_bwdin3<1>(p, weight, workspace, st);
+        case 2: return launch_bwdin3<2>(p, weight, workspace, st);
+        case 4: return launch_bwdin3<4>(p, weight, workspace, st);
+        default: return launch_bwdin3<8>(p, weight, workspace, st);
+    }
+}

@@ -86,4 +86,7 @@ int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);
 int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* bpart_or_null, int P, int nty, int gy, int gz,
                           hipStream_t st);
+size_t rvsr_dcn_bwdin3_workspace_bytes(int Co, int C);
+int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);
 extern int rvsr_g_gemm_mode;

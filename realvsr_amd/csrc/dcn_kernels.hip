@@ -428,7 +428,9 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     const int gy = (channels_out + 63) / 64, gz = (channels + DCN_CC - 1) / DCN_CC;
     const size_t Q = 8 * (size_t)bww_P(ntiles, gy, gz);
     const size_t a = sizeof(float) * Q * ((size_t)channels_out * channels * 9 + channels_out);
-    const size_t b2 = rvsr_dcn_bwdin2_workspace_bytes(channels_out, channels);
+    size_t b2 = rvsr_dcn_bwdin2_workspace_bytes(channels_out, channels);
+    const size_t b3 = rvsr_dcn_bwdin3_workspace_bytes(channels_out, channels);
+    if (b3 > b2) b2 = b3;
     return a > b2 ? a : b2;
 }
 
@@ -443,8 +445,11 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
-        if (rvsr_g_gemm_mode == 0)
-            rc2 = rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
+        if (rvsr_g_gemm_mode == 0) {
+            rc2 = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
+            if (rc2 == RVSR_ERR_UNSUPPORTED)
+                rc2 = rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
+        }
         if (rc2 != RVSR_ERR_UNSUPPORTED && rc2 != RVSR_OK) return rc2;
         DcnBwdInParams p;
         p.d = d; p.w = weight; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
