@@ -169,7 +169,9 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from realvsr_amd import loss as L
+    from realvsr_amd import _lib as rlib
     from realvsr_amd.dist import BucketedGradAllReduce
+    gemm_mode = rlib.get_gemm_mode()
     B, N, H, W = args.batch, args.nframes, args.height, args.width
     net = build_net(args.nf, N, args.back_rbs, device)
     x, gt = make_batch(B, N, H, W, device, rank)
@@ -221,14 +223,16 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'f32',  # tensors, accumulation and all non-GEMM math are f32; see config.gemm for the GEMM operands
             'data': 'synthetic',
             'config': {'workload': 'EDVR-M nf%d, %d-frame %dx%d LR windows, batch %d per GPU, x4 output, '
                                    'fwd + LapPyr(cb,cb)/Charbonnier loss + bwd + Adam step'
                                    % (args.nf, N, H, W, B),
                        'per_gpu_batch': B, 'global_batch': world * B, 'parallelism': 'sequence-dp%d' % world,
-                       'gemm': 'v_mfma_f32_32x32x2_f32 (exact f32)', 'loss_last_step': round(float(loss.item()), 6)},
-            'roofline': {'kernel': 'dcn_fwd_kernel', 'bound': 'hbm',
+                       'gemm': gemm_mode + (' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)'
+                                            if gemm_mode == 'bf16x3' else ' (v_mfma_f32_32x32x2_f32, exact f32)'),
+                       'loss_last_step': round(float(loss.item()), 6)},
+            'roofline': {'kernel': 'dcn_fwd2_kernel (+ its weight pre-pack), fused DCN forward', 'bound': 'hbm',
                          'achieved': round(kbytes / (kms * 1e-3) / 1e9, 2) if kms > 0 else None,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,

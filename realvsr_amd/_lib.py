@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-SO_PATH = os.path.join(_CSRC, 'librealvsr_hip.so')
+SO_PATH = os.environ.get('RVSR_SO', os.path.join(_CSRC, 'librealvsr_hip.so'))  # RVSR_SO: developer override for A/B builds
 _lib = None
 
 c_fp = ctypes.c_void_p  # device pointers travel as void*

@@ -20,9 +20,9 @@
 #include "bf16x3.h"
 
 // ------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int MT, int CCG>
-__global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd2_kernel(const ConvFwdParams p) {
-    constexpr int T = KS * KS, PAD = KS / 2, TH = 8, TW = 32;
+template <int KS, int STRIDE, int MT, int CCG, bool ACT_IN, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2, TH = 2 * NW, TW = 32, NTHR = NW * 64;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int MP = MT * 32, NOCT = 2 * CCG, NPOS = IH * IW;
     constexpr int WVEC = T * NOCT * MP;  // 16-byte vectors per weight part (hi or lo)
@@ -47,23 +47,28 @@ __global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd2_kernel(const ConvFwdPara
         acc[m][1] = zero16();
     }
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // Software pipeline: the global loads of chunk k+1 (input octets + packed weights) are issued right
+    // after the barrier that opens chunk k's MFMA phase and are only consumed (converted / written to
+    // LDS) after it, so HBM/L2 latency hides under the matrix-core work.
+    constexpr int NIT = (NOCT * NPOS + NTHR - 1) / NTHR;   // input items per thread
+    float vin[NIT][8];
+    float ain[ACT_IN ? NIT : 1][8];  // saved activation outputs (sign -> derivative), only for data gradients
+
+    auto issue_loads = [&](int chunk) {
         const int c0 = chunk * 16 * CCG;
-        // ---- weights: linear copy of the pre-packed LDS image (hi block then lo block)
-        {
-            const bf16x8* src = wsrc + (size_t)chunk * 2 * WVEC;
-#pragma unroll 4
-            for (int e = tid; e < 2 * WVEC; e += RVSR_WG) ws_hi[e] = src[e];
-        }
-        // ---- input tile: f32 NCHW -> bf16 hi/lo, [octet][row][col][8]
-        for (int it = tid; it < NOCT * NPOS; it += RVSR_WG) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = tid + i * NTHR;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                vin[i][j] = 0.f;
+                if (ACT_IN) ain[i][j] = 1.f;
+            }
+            if (it >= NOCT * NPOS) continue;
             const int oc = it / NPOS, pos = it - oc * NPOS;
             const int r = pos / IW, s = pos - r * IW;
             const int gy = y0 * STRIDE - PAD + r, gx = x0 * STRIDE - PAD + s;
             const int cb = c0 + oc * 8;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if (gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv && cb < Ctot) {
                 if (va.mode == 0) {
                     const bool first = cb < C1;  // octets never straddle the two inputs (C1 % 8 == 0)
@@ -74,11 +79,11 @@ __global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd2_kernel(const ConvFwdPara
                     const int nvalid = v0.C - cl;
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (j < nvalid) v[j] = v0.p[base + j * hw];
-                    if (v0.act != nullptr) {
+                        if (j < nvalid) vin[i][j] = v0.p[base + j * hw];
+                    if (ACT_IN) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            if (j < nvalid) v[j] *= (v0.act[base + j * hw] > 0.f ? 1.f : v0.slope);
+                            if (j < nvalid) ain[i][j] = v0.act[base + j * hw];
                     }
                 } else {  // mode 2: pixel-unshuffle view, virtual channel c -> stored (c>>2, 2y+((c>>1)&1), 2x+(c&1))
                     const size_t hw = (size_t)va.Hs * va.Ws;
@@ -86,18 +91,52 @@ __global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd2_kernel(const ConvFwdPara
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const size_t idx = base + (j >> 2) * hw + ((j >> 1) & 1) * va.Ws + (j & 1);
-                        float x = va.p[idx];
-                        if (va.act != nullptr) x *= (va.act[idx] > 0.f ? 1.f : va.slope);
-                        v[j] = x;
+                        vin[i][j] = va.p[idx];
+                        if (ACT_IN) ain[i][j] = va.act[idx];
                     }
                 }
             }
+        }
+    };
+    auto commit_to_lds = [&](int chunk) {
+        // packed weights: straight 16-byte copy (L2-resident); issued first so its latency overlaps the conversion below
+        const bf16x8* src = wsrc + (size_t)chunk * 2 * WVEC;
+#if !defined(RVSR_EXP) || RVSR_EXP != 1
+#pragma unroll 3
+        for (int e = tid; e < 2 * WVEC; e += NTHR) ws_hi[e] = src[e];
+#else
+        if (chunk == 0) for (int e = tid; e < 2 * WVEC; e += NTHR) ws_hi[e] = src[e];
+#endif
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = tid + i * NTHR;
+            if (it >= NOCT * NPOS) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ACT_IN ? vin[i][j] * (ain[i][j] > 0.f ? 1.f : va.slope) : vin[i][j];
             bf16x8 h8, l8;
+#if defined(RVSR_EXP) && RVSR_EXP == 5
+            if (v[0] == 12345.f)
+#endif
+            {
             split8(v, h8, l8);
             xs_hi[it] = h8;
             xs_lo[it] = l8;
+            }
         }
+    };
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        commit_to_lds(chunk);
         __syncthreads();
+#if defined(RVSR_EXP) && RVSR_EXP == 2
+        if (false)
+#endif
+        if (chunk + 1 < nchunks) issue_loads(chunk + 1);
+#if defined(RVSR_EXP) && RVSR_EXP == 3
+        if (p.B < 0)
+#endif
 #pragma unroll
         for (int tap = 0; tap < T; ++tap) {
             const int dy = tap / KS, dx = tap % KS;
@@ -116,19 +155,28 @@ __global__ __launch_bounds__(RVSR_WG, 2) void conv_fwd2_kernel(const ConvFwdPara
                     bh[n] = xs_hi[idx];
                     bl[n] = xs_lo[idx];
                 }
+                // the three split terms as three sweeps over the independent accumulators: consecutive
+                // MFMAs never depend on each other (a dependent 32x32x16 pair costs an extra pass group)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = mfma_bf16(ah[m], bh[n], acc[m][n]);
-                        acc[m][n] = mfma_bf16(ah[m], bl[n], acc[m][n]);
-                        acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
-                    }
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[m], bh[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[m], bl[n], acc[m][n]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
             }
         }
         __syncthreads();
     }
 
+#if defined(RVSR_EXP) && RVSR_EXP == 4
+    if (acc[0][0][0] != 12345.f) return;
+#endif
     if (p.ps)
         conv_epilogue<MT, 3>(acc, p, b, mb * MP, y0 + wave * 2, x0 + lo, hi);
     else if (p.out2 != nullptr)
@@ -156,13 +204,16 @@ size_t rvsr_conv_fwd2_workspace_bytes(int ksize, int Co, int Ctot) {
 
 template <int KS, int STRIDE, int MT, int CCG>
 static int launch_fwd2(const ConvFwdParams& p, hipStream_t st) {
-    constexpr int T = KS * KS, IH = 7 * STRIDE + KS, IW = 31 * STRIDE + KS;
+    // 8 waves (16 rows x 32 px) per workgroup for the common stride-1 3x3 case: the weight slice is
+    // amortised over twice the pixels and 2 workgroups/CU = 16 waves hide the staging latency better
+    constexpr int NW = 4;  // (8 waves / 16x32 px measured 5% slower: 1.07 vs 1.00 ms on the 40x64x180x320 conv)
+    constexpr int T = KS * KS, IH = (2 * NW - 1) * STRIDE + KS, IW = 31 * STRIDE + KS;
     const size_t lds = (size_t)16 * (2 * (2 * CCG) * IH * IW + 2 * T * (2 * CCG) * (MT * 32));
-    auto k = conv_fwd2_kernel<KS, STRIDE, MT, CCG>;
+    auto k = p.in.a.act != nullptr ? conv_fwd2_kernel<KS, STRIDE, MT, CCG, true, NW> : conv_fwd2_kernel<KS, STRIDE, MT, CCG, false, NW>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd2: cannot reserve %zu B of LDS", lds);
-    const int nty = (p.Hout + 7) / 8;
+    const int nty = (p.Hout + 2 * NW - 1) / (2 * NW);
     dim3 grid(p.ntx * nty, (p.Co + MT * 32 - 1) / (MT * 32), p.B);
-    hipLaunchKernelGGL(k, grid, dim3(RVSR_WG), lds, st, p);
+    hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_fwd2 launch: %s", hipGetErrorString(e));
     return RVSR_OK;
@@ -233,27 +284,26 @@ __device__ __forceinline__ bf16x8 take8(u32x4 a, u32x4 b) {
     return as_bf16x8(r);
 }
 
-// one (dy) row of taps for one accumulator group: DXMASK selects which dx (bit 0..2) this wave owns
+// one (dy) row of taps for one accumulator group: DXMASK selects which dx (bit 0..2) this wave owns.
+// The split terms are issued as sweeps over the row's independent accumulators (no back-to-back
+// dependent MFMAs).
 template <int DXMASK>
 __device__ __forceinline__ void wg2_row(const unsigned char* xs_hi, const unsigned char* xs_lo, int xoff, bf16x8 ah,
                                         bf16x8 al, f32x16* acc) {
     const u32x4 h0 = *reinterpret_cast<const u32x4*>(xs_hi + xoff), h1 = *reinterpret_cast<const u32x4*>(xs_hi + xoff + 16);
     const u32x4 l0 = *reinterpret_cast<const u32x4*>(xs_lo + xoff), l1 = *reinterpret_cast<const u32x4*>(xs_lo + xoff + 16);
+    constexpr int N = ((DXMASK >> 0) & 1) + ((DXMASK >> 1) & 1) + ((DXMASK >> 2) & 1);
+    bf16x8 bh[3], bl[3];
     int t = 0;
-    if (DXMASK & 1) {
-        const bf16x8 bh = take8<3>(h0, h1), bl = take8<3>(l0, l1);
-        acc[t] = mfma_bf16(ah, bh, acc[t]); acc[t] = mfma_bf16(ah, bl, acc[t]); acc[t] = mfma_bf16(al, bh, acc[t]);
-        ++t;
-    }
-    if (DXMASK & 2) {
-        const bf16x8 bh = take8<4>(h0, h1), bl = take8<4>(l0, l1);
-        acc[t] = mfma_bf16(ah, bh, acc[t]); acc[t] = mfma_bf16(ah, bl, acc[t]); acc[t] = mfma_bf16(al, bh, acc[t]);
-        ++t;
-    }
-    if (DXMASK & 4) {
-        const bf16x8 bh = take8<5>(h0, h1), bl = take8<5>(l0, l1);
-        acc[t] = mfma_bf16(ah, bh, acc[t]); acc[t] = mfma_bf16(ah, bl, acc[t]); acc[t] = mfma_bf16(al, bh, acc[t]);
-    }
+    if (DXMASK & 1) { bh[t] = take8<3>(h0, h1); bl[t] = take8<3>(l0, l1); ++t; }
+    if (DXMASK & 2) { bh[t] = take8<4>(h0, h1); bl[t] = take8<4>(l0, l1); ++t; }
+    if (DXMASK & 4) { bh[t] = take8<5>(h0, h1); bl[t] = take8<5>(l0, l1); ++t; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(ah, bh[i], acc[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(ah, bl[i], acc[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(al, bh[i], acc[i]);
 }
 
 __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvWgradParams p) {

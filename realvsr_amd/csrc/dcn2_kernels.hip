@@ -137,14 +137,18 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams
             }
             bf16x8 bh, bl;
             split8(v, bh, bl);
+            bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bf16x8 ah = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
-                const bf16x8 al = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
-                acc[mt] = mfma_bf16(ah, bh, acc[mt]);
-                acc[mt] = mfma_bf16(ah, bl, acc[mt]);
-                acc[mt] = mfma_bf16(al, bh, acc[mt]);
+                ah[mt] = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
+                al[mt] = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bh, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bl, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
         }
         __syncthreads();
     }

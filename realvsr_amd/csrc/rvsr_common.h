@@ -128,8 +128,20 @@ extern thread_local char rvsr_g_err[256];
         return code;                                           \
     } while (0)
 
+// opt a kernel into > 64 KB of dynamic LDS; the attribute call is made once per (kernel, size, device)
 template <typename K>
 static inline int set_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
-    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
+    static thread_local const void* last_k[8] = {nullptr};
+    static thread_local size_t last_b[8] = {0};
+    static thread_local int last_dev[8] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned slot = (unsigned)(((uintptr_t)(const void*)kernel >> 4) & 7);
+    if (last_k[slot] == (const void*)kernel && last_b[slot] >= bytes && last_dev[slot] == dev) return 0;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    last_k[slot] = (const void*)kernel;
+    last_b[slot] = bytes;
+    last_dev[slot] = dev;
+    return 0;
 }
