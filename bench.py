@@ -161,12 +161,21 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get('RVSR_BENCH_BACKEND', 'nccl')  # 'gloo': developer check of the N>1 path on one GPU
+    if backend == 'nccl' and world > ndev:
+        raise SystemExit('WORLD_SIZE=%d but only %d GPUs are visible (one rank per GPU)' % (world, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from realvsr_amd import loss as L
     from realvsr_amd import _lib as rlib

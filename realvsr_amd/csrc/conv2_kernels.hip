@@ -32,8 +32,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
     bf16x8* ws_hi = xs_lo + NOCT * NPOS;                  // [T][NOCT][MP]
     bf16x8* ws_lo = ws_hi + WVEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int tx = blockIdx.x % p.ntx, ty = blockIdx.x / p.ntx;
-    const int x0 = tx * TW, y0 = ty * TH, mb = blockIdx.y, b = blockIdx.z;
+    unsigned sbx, sby, sbz;
+    swizzled_block(sbx, sby, sbz, p.swz);
+    const int tx = sbx % p.ntx, ty = sbx / p.ntx;
+    const int x0 = tx * TW, y0 = ty * TH, mb = sby, b = sbz;
     const TView& va = p.in.a;
     const TView& vb = p.in.b;
     const int C1 = va.C, Ctot = va.C + vb.C;
@@ -231,6 +233,7 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, p.Co,
                        Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode);
     p.wpack = workspace;
+    p.swz = rvsr_swizzle_enabled();
 #define DISPATCH2(KS, S, CCG)                                   \
     do {                                                        \
         if (mt == 1) return launch_fwd2<KS, S, 1, CCG>(p, st);  \

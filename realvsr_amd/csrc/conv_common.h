@@ -7,6 +7,7 @@ struct ConvFwdParams {
     TCat in;
     const float* w;
     const void* wpack;  // bf16x3 path: packed weights (conv2_kernels.hip)
+    int swz;            // XCD-aware workgroup remap on/off
     const float* bias;
     const float* res;
     float* out1;

@@ -32,8 +32,10 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams
     bf16x8* ws_lo = ws_hi + WVEC;
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
-    const int x0 = tx * 32, y0 = ty * TH, mb = blockIdx.y, b = blockIdx.z;
+    unsigned sbx, sby, sbz;
+    swizzled_block(sbx, sby, sbz, d.swz);
+    const int tx = sbx % d.ntx, ty = sbx / d.ntx;
+    const int x0 = tx * 32, y0 = ty * TH, mb = sby, b = sbz;
     const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;  // image coords of tile (0,0)
     const int nchunks = (d.C + 15) / 16;
     const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
@@ -740,8 +742,10 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     bf16x8* wsb = reinterpret_cast<bf16x8*>(claim + D3_TH * 2 * PPOS);  // [3][WBLK]
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
-    const int x0 = tx * 32, y0 = ty * D3_TH, b = blockIdx.z;
+    unsigned sbx, sby, sbz;
+    swizzled_block(sbx, sby, sbz, d.swz);
+    const int tx = sbx % d.ntx, ty = sbx / d.ntx;
+    const int x0 = tx * 32, y0 = ty * D3_TH, b = sbz;
     const int ty0 = y0 - d.pad - D3_R, tx0 = x0 - d.pad - D3_R;  // stride 1
     const int nchunks = (d.C + 7) / 8;
     const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;

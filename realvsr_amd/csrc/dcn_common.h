@@ -15,6 +15,7 @@ struct DcnGeom {
     int B, C, H, W, Co, Ho, Wo;
     int stride, pad, dil, dg, cpg;
     int ntx;
+    int swz;  // XCD-aware workgroup remap on/off
 };
 
 struct Samp {

@@ -373,6 +373,7 @@ static int fill_geom(DcnGeom& d, const float* x, const float* offset, size_t off
     d.Wo = (W + 2 * pad_w - (dil_w * 2 + 1)) / stride_w + 1;
     if (d.Ho <= 0 || d.Wo <= 0) { *why = "empty output"; return RVSR_ERR_BAD_ARG; }
     d.ntx = (d.Wo + 31) / 32;
+    d.swz = rvsr_swizzle_enabled();
     return RVSR_OK;
 }
 

@@ -26,6 +26,24 @@ __device__ __forceinline__ f32x16 zero16() {
 // row of the 32x32 D tile held in register r of lane-half hi (= lane >> 5)
 __device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// XCD-aware workgroup remap (MI355X: 8 XCDs with private L2s, linear workgroup id L is observed to run on
+// XCD L % 8): give every XCD a CONTIGUOUS range of the (tile, m-block, batch) space so that the halo rows /
+// columns neighbouring tiles share are L2 hits instead of HBM re-reads.  Bijective for any N; affects
+// speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned L, unsigned N) {
+    const unsigned q = N >> 3, r = N & 7, xcd = L & 7, idx = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// decode the swizzled id of a (gx, gy, gz) grid
+__device__ __forceinline__ void swizzled_block(unsigned& bx, unsigned& by, unsigned& bz, int enable = 1) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, N = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned S = enable ? xcd_swizzle(L, N) : L;
+    bx = S % gx;
+    by = (S / gx) % gy;
+    bz = S / (gx * gy);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == 1) return v > 0.f ? v : 0.f;
     if (act == 2) return v > 0.f ? v : v * slope;
@@ -120,6 +138,16 @@ static inline void rvsr_launch_reduce(const float* part, int P, size_t n, float*
 }
 
 #include <stdio.h>
+#include <stdlib.h>
+// developer A/B switch: RVSR_XCD_SWIZZLE=0 disables the XCD-aware workgroup remap
+static inline int rvsr_swizzle_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RVSR_XCD_SWIZZLE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
 // one error string per host thread, shared by all translation units (defined in misc_kernels.hip)
 extern thread_local char rvsr_g_err[256];
 #define FAIL(code, ...)                                        \
