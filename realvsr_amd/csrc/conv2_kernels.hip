@@ -19,7 +19,66 @@
 
 #include "bf16x3.h"
 
+#ifdef RVSR_TIMELINE
+__device__ unsigned long long rvsr_dbg[256];
+extern "C" int rvsr_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg), sizeof(unsigned long long) * 256); }
+#define STAMP(i) do { if (blockIdx.x == 77 && tid == 0) rvsr_dbg[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
+// Epilogue of the bf16x3 kernel: bias comes from LDS (staged once per tile), residual values are fetched in
+// one batch per 32x32 tile before any store -- a per-element "load, wait, store" chain costs an L2 round trip
+// per element (measured 26 K cycles per tile for the 64 stores of a lane).
+template <int MT, int MODE>
+__device__ __forceinline__ void conv2_epilogue(f32x16 (&acc)[MT][2], const ConvFwdParams& p, const float* bias_s, int b,
+                                               int o0, int row0, int col, int hi) {
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+    const bool col_ok = col < p.Wout;
+    const size_t HW = (size_t)p.Hout * p.Wout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = row0 + n;
+        if (row >= p.Hout) continue;  // wave-uniform
+        const size_t pix = (size_t)row * p.Wout + col;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float resv[16];
+            if (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + m * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                    const bool ok = col_ok && o < p.Co;
+                    resv[r] = p.res[ok ? ((size_t)b * p.Co + o) * HW + pix : 0];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ol = m * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                const int o = o0 + ol;
+                const bool ok = col_ok && o < p.Co;
+                const int oc = ok ? o : 0;
+                float v = acc[m][n][r] + bias_s[ol];
+                v = v > 0.f ? v : v * neg;
+                if (MODE == 3) {
+                    const size_t idx = (((size_t)b * (p.Co >> 2) + (oc >> 2)) * (2 * p.Hout) + 2 * row + ((oc >> 1) & 1)) *
+                                           (2 * p.Wout) + 2 * col + (oc & 1);
+                    if (ok) p.out1[idx] = v;
+                } else if (MODE == 2) {
+                    const bool first = oc < p.Co1;
+                    float* dst = first ? p.out1 : p.out2;
+                    const size_t idx = ((size_t)b * (first ? p.Co1 : p.Co - p.Co1) + (first ? oc : oc - p.Co1)) * HW + pix;
+                    if (ok) dst[idx] = v;
+                } else {
+                    if (MODE == 1) v += resv[r];
+                    if (ok) p.out1[((size_t)b * p.Co + oc) * HW + pix] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int KS, int STRIDE, int MT, int CCG, bool ACT_IN, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdParams p) {
     constexpr int T = KS * KS, PAD = KS / 2, TH = 2 * NW, TW = 32, NTHR = NW * 64;
@@ -31,162 +90,205 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
     bf16x8* xs_lo = xs_hi + NOCT * NPOS;
     bf16x8* ws_hi = xs_lo + NOCT * NPOS;                  // [T][NOCT][MP]
     bf16x8* ws_lo = ws_hi + WVEC;
+    float* bias_s = reinterpret_cast<float*>(ws_lo + WVEC);  // [MP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    unsigned sbx, sby, sbz;
-    swizzled_block(sbx, sby, sbz, p.swz);
-    const int tx = sbx % p.ntx, ty = sbx / p.ntx;
-    const int x0 = tx * TW, y0 = ty * TH, mb = sby, b = sbz;
     const TView& va = p.in.a;
     const TView& vb = p.in.b;
     const int C1 = va.C, Ctot = va.C + vb.C;
     const int nchunks = (Ctot + 16 * CCG - 1) / (16 * CCG);
-    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(p.wpack) + (size_t)mb * nchunks * 2 * WVEC;
 
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        acc[m][0] = zero16();
-        acc[m][1] = zero16();
-    }
+    // ---- persistent schedule: the work items (tile, m-block, batch) are split into 8 contiguous ranges, one per
+    // XCD (workgroup w is observed on XCD w % 8: neighbouring tiles then share an L2); inside a range the XCD's
+    // workgroups take items round-robin.
+    const unsigned nmb = (p.Co + MP - 1) / MP, nty = (p.Hout + TH - 1) / TH;
+    const unsigned items = p.ntx * nty * nmb * p.B;
+    const unsigned xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, nwq = (gridDim.x + 7 - xcd) >> 3;
+    const unsigned q8 = items >> 3, r8 = items & 7;
+    const unsigned range0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned range1 = range0 + q8 + (xcd < r8 ? 1 : 0);
 
-    // Software pipeline: the global loads of chunk k+1 (input octets + packed weights) are issued right
-    // after the barrier that opens chunk k's MFMA phase and are only consumed (converted / written to
-    // LDS) after it, so HBM/L2 latency hides under the matrix-core work.
-    constexpr int NIT = (NOCT * NPOS + NTHR - 1) / NTHR;   // input items per thread
+    int x0 = 0, y0 = 0, mb = 0, b = 0;
+    auto decode = [&](unsigned S) {
+        const unsigned t = S % (p.ntx * nty);
+        x0 = (int)(t % p.ntx) * TW;
+        y0 = (int)(t / p.ntx) * TH;
+        mb = (int)((S / (p.ntx * nty)) % nmb);
+        b = (int)(S / (p.ntx * nty * nmb));
+    };
+
+    // ---- staging.  EVERY global load below is unconditional (addresses are clamped into the tensor, validity is
+    // kept as a count and applied when the value is written to LDS): a load inside a divergent `if` makes hipcc
+    // wait for it at the join, which serialises the loads of a thread into L2/HBM round trips (measured: 8 K
+    // cycles to "issue" 24 loads).  Loads of chunk k+1 are issued after the barrier that opens chunk k's MFMA
+    // phase and consumed only after it.
+    constexpr int NIT = (NOCT * NPOS + NTHR - 1) / NTHR;   // input items (octet x position) per thread
+    constexpr int NWV = (2 * WVEC + NTHR - 1) / NTHR;      // weight vectors per thread
     float vin[NIT][8];
     float ain[ACT_IN ? NIT : 1][8];  // saved activation outputs (sign -> derivative), only for data gradients
+    int nvalid[NIT];                 // number of real channels in the item's octet (0: position outside the image)
 
     auto issue_loads = [&](int chunk) {
         const int c0 = chunk * 16 * CCG;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int it = tid + i * NTHR;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                vin[i][j] = 0.f;
-                if (ACT_IN) ain[i][j] = 1.f;
-            }
-            if (it >= NOCT * NPOS) continue;
+            const int it_raw = tid + i * NTHR;
+            const bool live = it_raw < NOCT * NPOS;
+            const int it = live ? it_raw : 0;
             const int oc = it / NPOS, pos = it - oc * NPOS;
             const int r = pos / IW, s = pos - r * IW;
             const int gy = y0 * STRIDE - PAD + r, gx = x0 * STRIDE - PAD + s;
             const int cb = c0 + oc * 8;
-            if (gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv && cb < Ctot) {
-                if (va.mode == 0) {
-                    const bool first = cb < C1;  // octets never straddle the two inputs (C1 % 8 == 0)
-                    const TView& v0 = first ? va : vb;
-                    const int cl = first ? cb : cb - C1;
-                    const size_t hw = (size_t)v0.Hs * v0.Ws;
-                    const size_t base = ((size_t)b * v0.C + cl) * hw + (size_t)gy * v0.Ws + gx;
-                    const int nvalid = v0.C - cl;
+            const bool inb = live && gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv && cb < Ctot;
+            const int gyc = gy < 0 ? 0 : (gy >= va.Hv ? va.Hv - 1 : gy), gxc = gx < 0 ? 0 : (gx >= va.Wv ? va.Wv - 1 : gx);
+            if (va.mode == 0) {  // (uniform branch)
+                const bool second = inb && cb >= C1;  // octets never straddle the two inputs (C1 % 8 == 0)
+                const float* bp = second ? vb.p : va.p;
+                const float* ap = va.act;             // act' fusion only exists for single-input data gradients
+                const int Cb = second ? vb.C : va.C;
+                const int cl = inb ? (second ? cb - C1 : cb) : 0;
+                const size_t hw = (size_t)va.Hs * va.Ws;
+                const size_t sp = (size_t)gyc * va.Ws + gxc;
+                nvalid[i] = inb ? (Cb - cl < 8 ? Cb - cl : 8) : 0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j < nvalid) vin[i][j] = v0.p[base + j * hw];
-                    if (ACT_IN) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (j < nvalid) ain[i][j] = v0.act[base + j * hw];
-                    }
-                } else {  // mode 2: pixel-unshuffle view, virtual channel c -> stored (c>>2, 2y+((c>>1)&1), 2x+(c&1))
-                    const size_t hw = (size_t)va.Hs * va.Ws;
-                    const size_t base = ((size_t)b * (va.C >> 2) + (cb >> 2)) * hw + (size_t)(2 * gy) * va.Ws + 2 * gx;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const size_t idx = base + (j >> 2) * hw + ((j >> 1) & 1) * va.Ws + (j & 1);
-                        vin[i][j] = va.p[idx];
-                        if (ACT_IN) ain[i][j] = va.act[idx];
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int cj = cl + j < Cb ? cl + j : Cb - 1;
+                    const size_t idx = ((size_t)b * Cb + cj) * hw + sp;
+                    vin[i][j] = bp[idx];
+                    if (ACT_IN) ain[i][j] = ap[idx];
                 }
+            } else {  // mode 2: pixel-unshuffle view, virtual channel c -> stored (c>>2, 2y+((c>>1)&1), 2x+(c&1))
+                const size_t hw = (size_t)va.Hs * va.Ws;
+                const int cbc = inb ? cb : 0;
+                const size_t base = ((size_t)b * (va.C >> 2) + (cbc >> 2)) * hw + (size_t)(2 * gyc) * va.Ws + 2 * gxc;
+                nvalid[i] = inb ? 8 : 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const size_t idx = base + (j >> 2) * hw + ((j >> 1) & 1) * va.Ws + (j & 1);
+                    vin[i][j] = va.p[idx];
+                    if (ACT_IN) ain[i][j] = va.act[idx];
+                }
+            }
+        }
+    };
+    auto commit_inputs = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = tid + i * NTHR;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = ACT_IN ? vin[i][j] * (ain[i][j] > 0.f ? 1.f : va.slope) : vin[i][j];
+                v[j] = j < nvalid[i] ? x : 0.f;
+            }
+            bf16x8 h8, l8;
+            split8(v, h8, l8);
+            if (it < NOCT * NPOS) {
+                xs_hi[it] = h8;
+                xs_lo[it] = l8;
             }
         }
     };
     auto commit_to_lds = [&](int chunk) {
-        // packed weights: straight 16-byte copy (L2-resident); issued first so its latency overlaps the conversion below
-        const bf16x8* src = wsrc + (size_t)chunk * 2 * WVEC;
-#if !defined(RVSR_EXP) || RVSR_EXP != 1
-#pragma unroll 3
-        for (int e = tid; e < 2 * WVEC; e += NTHR) ws_hi[e] = src[e];
-#else
-        if (chunk == 0) for (int e = tid; e < 2 * WVEC; e += NTHR) ws_hi[e] = src[e];
-#endif
+        // packed weights: straight 16-byte copy (L2-resident), in batches of <= 9 vectors per thread: all loads of
+        // a batch are issued before its LDS writes.  When registers allow (forward variants) the first batch's
+        // loads fly while the input tile is converted.
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(p.wpack) + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
+        constexpr int WB = MT >= 4 ? 3 : 9;  // MT = 4 keeps 128 accumulator registers live: smaller batches
+        constexpr bool OVERLAP = !ACT_IN && MT <= 2;
+        if (!OVERLAP) commit_inputs();
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int it = tid + i * NTHR;
-            if (it >= NOCT * NPOS) continue;
-            float v[8];
+        for (int base = 0; base < NWV; base += WB) {
+            bf16x8 wv[WB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ACT_IN ? vin[i][j] * (ain[i][j] > 0.f ? 1.f : va.slope) : vin[i][j];
-            bf16x8 h8, l8;
-#if defined(RVSR_EXP) && RVSR_EXP == 5
-            if (v[0] == 12345.f)
-#endif
-            {
-            split8(v, h8, l8);
-            xs_hi[it] = h8;
-            xs_lo[it] = l8;
+            for (int i = 0; i < WB; ++i) {
+                const int e = tid + (base + i) * NTHR;
+                wv[i] = src[(base + i < NWV && e < 2 * WVEC) ? e : 0];
             }
+            if (OVERLAP && base == 0) commit_inputs();
+#pragma unroll
+            for (int i = 0; i < WB; ++i) {
+                const int e = tid + (base + i) * NTHR;
+                if (base + i < NWV && e < 2 * WVEC) ws_hi[e] = wv[i];
+            }
+        }
+        if (chunk == 0 && tid < MP) {
+            const int o = mb * MP + tid;
+            bias_s[tid] = (p.bias != nullptr && o < p.Co) ? p.bias[o] : 0.f;
         }
     };
 
-    issue_loads(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        commit_to_lds(chunk);
-        __syncthreads();
-#if defined(RVSR_EXP) && RVSR_EXP == 2
-        if (false)
-#endif
-        if (chunk + 1 < nchunks) issue_loads(chunk + 1);
-#if defined(RVSR_EXP) && RVSR_EXP == 3
-        if (p.B < 0)
-#endif
+    // register prefetch only where the register file has room for it; the other variants stage synchronously
+    constexpr bool PF = !ACT_IN && MT <= 2;
+    unsigned S = range0 + wq;
+    if (S < range1) {
+        decode(S);
+        if (PF) issue_loads(0);
+    }
+    for (; S < range1; S += nwq) {
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int tap = 0; tap < T; ++tap) {
-            const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-            for (int g = 0; g < CCG; ++g) {
-                const int oc = 2 * g + hi;
-                bf16x8 ah[MT], al[MT], bh[2], bl[2];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ah[m] = ws_hi[(tap * NOCT + oc) * MP + m * 32 + lo];
-                    al[m] = ws_lo[(tap * NOCT + oc) * MP + m * 32 + lo];
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int idx = (oc * IH + (wave * 2 + n) * STRIDE + dy) * IW + lo * STRIDE + dx;
-                    bh[n] = xs_hi[idx];
-                    bl[n] = xs_lo[idx];
-                }
-                // the three split terms as three sweeps over the independent accumulators: consecutive
-                // MFMAs never depend on each other (a dependent 32x32x16 pair costs an extra pass group)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[m], bh[n], acc[m][n]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[m], bl[n], acc[m][n]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
-            }
+        for (int m = 0; m < MT; ++m) {
+            acc[m][0] = zero16();
+            acc[m][1] = zero16();
         }
+        const int cx0 = x0, cy0 = y0, cmb = mb, cb_ = b;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (!PF) issue_loads(chunk);
+            commit_to_lds(chunk);
+            __syncthreads();
+            if (PF && chunk + 1 < nchunks) issue_loads(chunk + 1);
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+                for (int g = 0; g < CCG; ++g) {
+                    const int oc = 2 * g + hi;
+                    bf16x8 ah[MT], al[MT], bh[2], bl[2];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        ah[m] = ws_hi[(tap * NOCT + oc) * MP + m * 32 + lo];
+                        al[m] = ws_lo[(tap * NOCT + oc) * MP + m * 32 + lo];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int idx = (oc * IH + (wave * 2 + n) * STRIDE + dy) * IW + lo * STRIDE + dx;
+                        bh[n] = xs_hi[idx];
+                        bl[n] = xs_lo[idx];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[m], bh[n], acc[m][n]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[m], bl[n], acc[m][n]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
+                }
+            }
+            __syncthreads();
+        }
+        if (p.ps)
+            conv2_epilogue<MT, 3>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        else if (p.out2 != nullptr)
+            conv2_epilogue<MT, 2>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        else if (p.res != nullptr)
+            conv2_epilogue<MT, 1>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        else
+            conv2_epilogue<MT, 0>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        if (S + nwq < range1) {  // the stores above are asynchronous: the next tile's loads go out right behind them
+            decode(S + nwq);
+            if (PF) issue_loads(0);
+        }
+        // bias_s of this tile is read by the epilogue above and rewritten by the next tile's chunk-0 commit:
+        // that commit is followed by a barrier before any MFMA, and every wave passed the last barrier of this
+        // tile before its epilogue; a wave still in its epilogue while another already commits the next tile
+        // would race on bias_s, hence one more barrier.
         __syncthreads();
     }
-
-#if defined(RVSR_EXP) && RVSR_EXP == 4
-    if (acc[0][0][0] != 12345.f) return;
-#endif
-    if (p.ps)
-        conv_epilogue<MT, 3>(acc, p, b, mb * MP, y0 + wave * 2, x0 + lo, hi);
-    else if (p.out2 != nullptr)
-        conv_epilogue<MT, 2>(acc, p, b, mb * MP, y0 + wave * 2, x0 + lo, hi);
-    else if (p.res != nullptr)
-        conv_epilogue<MT, 1>(acc, p, b, mb * MP, y0 + wave * 2, x0 + lo, hi);
-    else
-        conv_epilogue<MT, 0>(acc, p, b, mb * MP, y0 + wave * 2, x0 + lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -210,11 +312,13 @@ static int launch_fwd2(const ConvFwdParams& p, hipStream_t st) {
     // amortised over twice the pixels and 2 workgroups/CU = 16 waves hide the staging latency better
     constexpr int NW = 4;  // (8 waves / 16x32 px measured 5% slower: 1.07 vs 1.00 ms on the 40x64x180x320 conv)
     constexpr int T = KS * KS, IH = (2 * NW - 1) * STRIDE + KS, IW = 31 * STRIDE + KS;
-    const size_t lds = (size_t)16 * (2 * (2 * CCG) * IH * IW + 2 * T * (2 * CCG) * (MT * 32));
+    const size_t lds = (size_t)16 * (2 * (2 * CCG) * IH * IW + 2 * T * (2 * CCG) * (MT * 32)) + sizeof(float) * MT * 32;
     auto k = p.in.a.act != nullptr ? conv_fwd2_kernel<KS, STRIDE, MT, CCG, true, NW> : conv_fwd2_kernel<KS, STRIDE, MT, CCG, false, NW>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd2: cannot reserve %zu B of LDS", lds);
     const int nty = (p.Hout + 2 * NW - 1) / (2 * NW);
-    dim3 grid(p.ntx * nty, (p.Co + MT * 32 - 1) / (MT * 32), p.B);
+    const long items = (long)p.ntx * nty * ((p.Co + MT * 32 - 1) / (MT * 32)) * p.B;
+    const int slots = 256 * (lds > 80 * 1024 ? 1 : 2);  // persistent: 2 workgroups per CU when LDS allows
+    dim3 grid((unsigned)(items < slots ? items : slots), 1, 1);
     hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_fwd2 launch: %s", hipGetErrorString(e));
@@ -309,6 +413,7 @@ __device__ __forceinline__ void wg2_row(const unsigned char* xs_hi, const unsign
     for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(al, bh[i], acc[i]);
 }
 
+template <bool ACT, int GMODE>
 __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvWgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* gs_hi = smem_raw;                  // [64 o][WG2_GP]
@@ -331,60 +436,110 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     if (tid < 64) bsum[tid] = 0.f;
     __syncthreads();
 
-    const int ntiles = p.B * p.nty * p.ntx;
-    for (int tile = blockIdx.x; tile < ntiles; tile += p.P) {
+    // ---- staging registers.  All global loads are unconditional 16-byte loads from clamped addresses (a load
+    // inside a divergent `if` is waited for at the join); validity travels as flags and is applied on the way to
+    // LDS.  The loads of tile t+1 are issued after the barrier that opens tile t's MFMA phase.
+    constexpr int NGI = 2;                  // G items per thread: 64 o x 4 rows x 4 octets / 512
+    constexpr int NGV = GMODE == 0 ? 2 : 4; // float4 per G item (8 virtual px; pixel-shuffled storage holds 16 floats)
+    constexpr int NXI = 4;                  // X items per thread: 64 c x 6 rows x 5 octets = 1920 / 512 -> 3.75
+    float4 gv[NGI][NGV], sv[ACT ? NGI : 1][NGV], xv[NXI][2];
+    unsigned gok = 0, xok = 0;              // bit (i * 4 + k): float4 k of item i is inside the image
+
+    auto issue_loads = [&](int tile) {
         const int b = tile / (p.nty * p.ntx);
         const int trem = tile - b * (p.nty * p.ntx);
         const int ty = trem / p.ntx, tx = trem - ty * p.ntx;
         const int y0 = ty * 4, x0 = tx * 32;
-        // ---- G tile: 64 o x 4 rows x 4 octets
-        for (int it = tid; it < 64 * 16; it += WG2_THREADS) {
+        gok = 0;
+        xok = 0;
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+            const int it = tid + i * WG2_THREADS;
             const int q = it & 3, row = (it >> 2) & 3, ol = it >> 4;
             const int o = mb * 64 + ol, gy = y0 + row, gx = x0 + 8 * q;
+            const bool ok = o < p.Co && gy < H;
+            if (GMODE == 0) {
+                const size_t base = ok ? (((size_t)b * p.Co + o) * H + gy) * W : 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bool okk = ok && gx + 4 * k < W;
+                    const size_t idx = okk ? base + gx + 4 * k : 0;
+                    gv[i][k] = *reinterpret_cast<const float4*>(p.g.p + idx);
+                    if (ACT) sv[i][k] = *reinterpret_cast<const float4*>(p.g.act + idx);
+                    gok |= (okk ? 1u : 0u) << (i * 4 + k);
+                }
+            } else {  // stored (Co/4, 2H, 2W) pixel-shuffled: 8 virtual px = 16 stored floats, every other one
+                const size_t base = ok ? (((size_t)b * (p.Co >> 2) + (o >> 2)) * (2 * H) + 2 * gy + ((o >> 1) & 1)) * (size_t)(2 * W) : 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool okk = ok && gx + 2 * k < W;
+                    const size_t idx = okk ? base + 2 * gx + 4 * k : 0;
+                    gv[i][k] = *reinterpret_cast<const float4*>(p.g.p + idx);
+                    if (ACT) sv[i][k] = *reinterpret_cast<const float4*>(p.g.act + idx);
+                    gok |= (okk ? 1u : 0u) << (i * 4 + k);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int it_raw = tid + i * WG2_THREADS;
+            const bool live = it_raw < 64 * 30;
+            const int it = live ? it_raw : 0;
+            const int cl = it / 30, rem = it - cl * 30;
+            const int row = rem / 5, q = rem - row * 5;
+            const int c = c0 + cl, gy = y0 - 1 + row, gx = x0 - 4 + 8 * q;
+            const bool ok = live && c < Ctot && gy >= 0 && gy < H;
+            const bool sec = ok && c >= C1;
+            const float* src = sec ? p.x.b.p : p.x.a.p;
+            const size_t base = ok ? (((size_t)b * (sec ? Ctot - C1 : C1) + (sec ? c - C1 : c)) * H + gy) * W : 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int gxx = gx + 4 * k;
+                const bool okk = ok && gxx >= 0 && gxx < W;
+                xv[i][k] = *reinterpret_cast<const float4*>(src + (okk ? base + gxx : 0));
+                xok |= (okk ? 1u : 0u) << (i * 4 + k);
+            }
+        }
+    };
+
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+            const int it = tid + i * WG2_THREADS;
+            const int q = it & 3, row = (it >> 2) & 3, ol = it >> 4;
             float v[8];
+            if (GMODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            if (o < p.Co && gy < H && gx < W) {
-                if (p.g.mode == 0) {
-                    const size_t idx = (((size_t)b * p.Co + o) * H + gy) * W + gx;
-                    const float4 a0 = *reinterpret_cast<const float4*>(p.g.p + idx);
-                    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
-                    if (gx + 4 < W) {
-                        const float4 a1 = *reinterpret_cast<const float4*>(p.g.p + idx + 4);
-                        v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+                for (int k = 0; k < 2; ++k) {
+                    const bool okk = (gok >> (i * 4 + k)) & 1;
+                    float4 a = gv[i][k];
+                    if (ACT) {
+                        const float4 s_ = sv[i][k];
+                        a.x *= s_.x > 0.f ? 1.f : p.g.slope; a.y *= s_.y > 0.f ? 1.f : p.g.slope;
+                        a.z *= s_.z > 0.f ? 1.f : p.g.slope; a.w *= s_.w > 0.f ? 1.f : p.g.slope;
                     }
-                    if (p.g.act != nullptr) {
-                        const float4 s0 = *reinterpret_cast<const float4*>(p.g.act + idx);
-                        v[0] *= s0.x > 0.f ? 1.f : p.g.slope; v[1] *= s0.y > 0.f ? 1.f : p.g.slope;
-                        v[2] *= s0.z > 0.f ? 1.f : p.g.slope; v[3] *= s0.w > 0.f ? 1.f : p.g.slope;
-                        if (gx + 4 < W) {
-                            const float4 s1 = *reinterpret_cast<const float4*>(p.g.act + idx + 4);
-                            v[4] *= s1.x > 0.f ? 1.f : p.g.slope; v[5] *= s1.y > 0.f ? 1.f : p.g.slope;
-                            v[6] *= s1.z > 0.f ? 1.f : p.g.slope; v[7] *= s1.w > 0.f ? 1.f : p.g.slope;
-                        }
-                    }
-                } else {  // mode 2: stored (Co/4, 2H, 2W) pixel-shuffled; 8 virtual px = 16 stored floats, every other one
-                    const size_t idx = (((size_t)b * (p.Co >> 2) + (o >> 2)) * (2 * H) + 2 * gy + ((o >> 1) & 1)) * (size_t)(2 * W) + 2 * gx;
-                    const int sx = o & 1;
+                    v[4 * k + 0] = okk ? a.x : 0.f; v[4 * k + 1] = okk ? a.y : 0.f;
+                    v[4 * k + 2] = okk ? a.z : 0.f; v[4 * k + 3] = okk ? a.w : 0.f;
+                }
+            } else {
+                const int sx = (mb * 64 + ol) & 1;
 #pragma unroll
-                    for (int h4 = 0; h4 < 4; ++h4) {
-                        if (gx + 2 * h4 < W) {
-                            const float4 a = *reinterpret_cast<const float4*>(p.g.p + idx + 4 * h4);
-                            float e0 = sx ? a.y : a.x, e1 = sx ? a.w : a.z;
-                            if (p.g.act != nullptr) {
-                                const float4 s = *reinterpret_cast<const float4*>(p.g.act + idx + 4 * h4);
-                                e0 *= (sx ? s.y : s.x) > 0.f ? 1.f : p.g.slope;
-                                e1 *= (sx ? s.w : s.z) > 0.f ? 1.f : p.g.slope;
-                            }
-                            v[2 * h4] = e0;
-                            v[2 * h4 + 1] = e1;
-                        }
+                for (int k = 0; k < 4; ++k) {
+                    const bool okk = (gok >> (i * 4 + k)) & 1;
+                    const float4 a = gv[i][k];
+                    float e0 = sx ? a.y : a.x, e1 = sx ? a.w : a.z;
+                    if (ACT) {
+                        const float4 s_ = sv[i][k];
+                        e0 *= (sx ? s_.y : s_.x) > 0.f ? 1.f : p.g.slope;
+                        e1 *= (sx ? s_.w : s_.z) > 0.f ? 1.f : p.g.slope;
                     }
+                    v[2 * k] = okk ? e0 : 0.f;
+                    v[2 * k + 1] = okk ? e1 : 0.f;
                 }
             }
             if (do_bias) {
-                const float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                atomicAdd(&bsum[ol], s);
+                const float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                atomicAdd(&bsum[ol], sm);
             }
             bf16x8 h8, l8;
             split8(v, h8, l8);
@@ -392,25 +547,19 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             *reinterpret_cast<bf16x8*>(gs_hi + off) = h8;
             *reinterpret_cast<bf16x8*>(gs_lo + off) = l8;
         }
-        // ---- X tile: 64 c x 6 rows x 5 octets, columns x0-4 .. x0+35
-        for (int it = tid; it < 64 * 30; it += WG2_THREADS) {
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int it = tid + i * WG2_THREADS;
+            if (it >= 64 * 30) continue;
             const int cl = it / 30, rem = it - cl * 30;
             const int row = rem / 5, q = rem - row * 5;
-            const int c = c0 + cl, gy = y0 - 1 + row, gx = x0 - 4 + 8 * q;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            if (c < Ctot && gy >= 0 && gy < H) {
-                const float* src = c < C1 ? p.x.a.p + ((size_t)b * C1 + c) * H * W : p.x.b.p + ((size_t)b * (Ctot - C1) + (c - C1)) * H * W;
-                src += (size_t)gy * W;
-                if (gx >= 0 && gx < W) {
-                    const float4 a = *reinterpret_cast<const float4*>(src + gx);
-                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-                }
-                if (gx + 4 >= 0 && gx + 4 < W) {
-                    const float4 a = *reinterpret_cast<const float4*>(src + gx + 4);
-                    v[4] = a.x; v[5] = a.y; v[6] = a.z; v[7] = a.w;
-                }
+            for (int k = 0; k < 2; ++k) {
+                const bool okk = (xok >> (i * 4 + k)) & 1;
+                const float4 a = xv[i][k];
+                v[4 * k + 0] = okk ? a.x : 0.f; v[4 * k + 1] = okk ? a.y : 0.f;
+                v[4 * k + 2] = okk ? a.z : 0.f; v[4 * k + 3] = okk ? a.w : 0.f;
             }
             bf16x8 h8, l8;
             split8(v, h8, l8);
@@ -418,7 +567,17 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             *reinterpret_cast<bf16x8*>(xs_hi + off) = h8;
             *reinterpret_cast<bf16x8*>(xs_lo + off) = l8;
         }
+    };
+
+    // contiguous tile range per workgroup: consecutive tiles share halo rows/columns in L2
+    const int ntiles = p.B * p.nty * p.ntx;
+    const int per = (ntiles + p.P - 1) / p.P;
+    const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+    if (t_begin < t_end) issue_loads(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        commit();
         __syncthreads();
+        if (tile + 1 < t_end) issue_loads(tile + 1);
         if (m_live) {
 #pragma unroll 2
             for (int ks = 0; ks < 8; ++ks) {
@@ -462,8 +621,11 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
 
 int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_t st) {
     const size_t lds = 2 * 64 * WG2_GP + 2 * 64 * WG2_XP + 64 * sizeof(float);
-    if (set_lds(conv_wgrad2_kernel, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(conv_wgrad2_kernel, dim3(p.P, gy, gz), dim3(WG2_THREADS), lds, st, p);
+    const bool act = p.g.act != nullptr;
+    auto k = p.g.mode == 0 ? (act ? conv_wgrad2_kernel<true, 0> : conv_wgrad2_kernel<false, 0>)
+                           : (act ? conv_wgrad2_kernel<true, 2> : conv_wgrad2_kernel<false, 2>);
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(k, dim3(p.P, gy, gz), dim3(WG2_THREADS), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2 launch: %s", hipGetErrorString(e));
     return RVSR_OK;
