@@ -294,7 +294,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
 // ------------------------------------------------------------------------------------------
 // host side (called from conv_kernels.hip)
 static void fwd2_geom(int ksize, int Co, int Ctot, int& mt, int& ccg, int& nchunks, int& nmb) {
-    mt = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+    // never more than 2 M tiles per workgroup: the MT = 4 instantiation keeps 128 accumulator registers live and
+    // spills (130-190 VGPRs to scratch); two 64-row m-blocks re-stage the input tile but run spill-free
+    mt = Co <= 32 ? 1 : 2;
     ccg = ksize == 3 ? 1 : 2;
     nchunks = (Ctot + 16 * ccg - 1) / (16 * ccg);
     nmb = (Co + mt * 32 - 1) / (mt * 32);
