@@ -19,10 +19,59 @@
 #include "bf16x3.h"
 #include "dcn_common.h"
 
+#ifdef RVSR_TIMELINE_DCN
+__device__ unsigned long long rvsr_dbg_dcn[256];
+extern "C" int rvsr_debug_read_dcn(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_dcn), sizeof(unsigned long long) * 256); }
+#define DSTAMP(i) do { if (blockIdx.x == 77 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DSTAMP(i) do {} while (0)
+#endif
+
 #define D2_R 3  // halo radius (pixels) of the LDS x tile beyond the 3x3 footprint
 
+// Stage the x tile of NQ channel quads (channels c0 .. c0+4*NQ-1) into LDS as [quad][row][col] float4.
+// All global loads are unconditional (addresses clamped into the tensor, validity applied afterwards) and are
+// issued in batches before any LDS write: a load inside a divergent `if` is waited for at the join, which turns
+// the staging loop into one HBM/L2 round trip per item.
+template <int NT, int NQ, int TR, int TC>
+__device__ __forceinline__ void stage_x_tile(float4* xt, const DcnGeom& d, int b, int c0, int ty0, int tx0, int tid) {
+    constexpr int NPOS = TR * TC, NITEMS = NQ * NPOS, PER = (NITEMS + NT - 1) / NT, BATCH = PER < 6 ? PER : 5;
+    const size_t HW = (size_t)d.H * d.W;
+#pragma unroll
+    for (int base = 0; base < PER; base += BATCH) {
+        float v[BATCH][4];
+        int nv[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int it_raw = tid + (base + k) * NT;
+            const bool live = (base + k < PER) && it_raw < NITEMS;
+            const int it = live ? it_raw : 0;
+            const int quad = it / NPOS, pos = it - quad * NPOS;
+            const int r = pos / TC, s = pos - r * TC;
+            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
+            const bool inb = live && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C;
+            const int gyc = gy < 0 ? 0 : (gy >= d.H ? d.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= d.W ? d.W - 1 : gx);
+            const int cbc = inb ? cb : 0;
+            const float* src = d.x + ((size_t)b * d.C) * HW + (size_t)gyc * d.W + gxc;
+            nv[k] = inb ? (d.C - cb < 4 ? d.C - cb : 4) : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = cbc + e < d.C ? cbc + e : d.C - 1;
+                v[k][e] = src[(size_t)c * HW];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int it = tid + (base + k) * NT;
+            if ((base + k < PER) && it < NITEMS)
+                xt[it] = make_float4(nv[k] > 0 ? v[k][0] : 0.f, nv[k] > 1 ? v[k][1] : 0.f, nv[k] > 2 ? v[k][2] : 0.f,
+                                     nv[k] > 3 ? v[k][3] : 0.f);
+        }
+    }
+}
+
 template <int TH, int MT>
-__global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
+__global__ __launch_bounds__(TH * 64, MT <= 2 ? 4 : 2) void dcn_fwd2_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int NT = TH * 64;
     constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
     constexpr int MP = MT * 32, WVEC = 9 * 2 * MP;  // 16-byte vectors per weight part
@@ -30,6 +79,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams
     float4* xt = reinterpret_cast<float4*>(smem_raw);           // [2 octets][2 halves][NPOS]
     bf16x8* ws_hi = reinterpret_cast<bf16x8*>(xt + 4 * NPOS);   // [9 taps][2 octets][MP]
     bf16x8* ws_lo = ws_hi + WVEC;
+    float* bias_s = reinterpret_cast<float*>(ws_lo + WVEC);  // [MP]
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     unsigned sbx, sby, sbz;
@@ -47,48 +97,51 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = zero16();
 
+    DSTAMP(0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * 16;
-        {   // weight slice: linear copy of the pre-packed LDS image (hi block, then lo block)
-            const bf16x8* src = wpack + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
-#pragma unroll 4
-            for (int e = tid; e < 2 * WVEC; e += NT) ws_hi[e] = src[e];
-        }
-        // x tile of the chunk's 16 channels: item = (quad of 4 channels, position)
-        for (int it = tid; it < 4 * NPOS; it += NT) {
-            const int quad = it / NPOS, pos = it - quad * NPOS;
-            const int r = pos / TC, s = pos - r * TC;
-            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
-                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
-                v.x = src[0];
-                if (cb + 1 < d.C) v.y = src[HW];
-                if (cb + 2 < d.C) v.z = src[2 * HW];
-                if (cb + 3 < d.C) v.w = src[3 * HW];
-            }
-            xt[it] = v;
-        }
-        __syncthreads();
-
         const int cb8 = c0 + 8 * hi;              // first channel of this lane's octet
         const bool oct_ok = px_ok && cb8 < d.C;
         const int g = oct_ok ? cb8 / d.cpg : 0;
-        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pix;
-        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pix;
+        // offsets / mask pointers (clamped to pixel 0 for lanes outside the image: loads stay unconditional);
+        // tap 0's values are requested before the staging below, tap t+1's under tap t's math.  (Fetching all 9
+        // taps up front was measured slower: +27 live registers -> spills at the 128-VGPR / 4-waves-per-SIMD point.)
+        const size_t pixc = oct_ok ? pix : 0;
+        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pixc;
+        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pixc;
+        float n_dy = offp[0], n_dx = offp[hw], n_m = mskp[0];
+        {   // weight slice: linear copy of the pre-packed LDS image (hi block, then lo block)
+            const bf16x8* src = wpack + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
+            constexpr int NWV = (2 * WVEC + NT - 1) / NT;
+            bf16x8 wv[NWV];
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int e = tid + i * NT;
+                wv[i] = src[e < 2 * WVEC ? e : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int e = tid + i * NT;
+                if (e < 2 * WVEC) ws_hi[e] = wv[i];
+            }
+            if (chunk == 0 && tid < MP) {
+                const int o = mb * MP + tid;
+                bias_s[tid] = (p.bias != nullptr && o < d.Co) ? p.bias[o] : 0.f;
+            }
+        }
+        DSTAMP(1 + chunk * 5);
+        stage_x_tile<NT, 4, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
+        DSTAMP(2 + chunk * 5);
+        __syncthreads();
+        DSTAMP(3 + chunk * 5);
+
         const float4* xq0 = xt + (2 * hi) * NPOS;  // channels cb8..cb8+3
         const float4* xq1 = xq0 + NPOS;            // channels cb8+4..cb8+7
-        float n_dy = 0.f, n_dx = 0.f, n_m = 0.f;
-        if (oct_ok) {
-            n_dy = offp[0];
-            n_dx = offp[hw];
-            n_m = mskp[0];
-        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float dy = n_dy, dx = n_dx;
             float m = n_m;
-            if (tap < 8 && oct_ok) {  // prefetch the next tap's offsets/mask under this tap's math
+            if (tap < 8) {  // (compile-time) prefetch the next tap's offsets/mask under this tap's math
                 n_dy = offp[(size_t)(2 * tap + 2) * hw];
                 n_dx = offp[(size_t)(2 * tap + 3) * hw];
                 n_m = mskp[(size_t)(tap + 1) * hw];
@@ -152,27 +205,27 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_fwd2_kernel(const DcnFwdParams
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
         }
+        DSTAMP(4 + chunk * 5);
         __syncthreads();
+        DSTAMP(5 + chunk * 5);
     }
 
     if (oy >= d.Ho) return;
-    const bool has_bias = p.bias != nullptr;
-    const float* bp = has_bias ? p.bias : p.w;
     const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int o = mb * MP + mt * 32 + drow(r, hi);
+            const int ol = mt * 32 + drow(r, hi);
+            const int o = mb * MP + ol;
             const bool ok = ox < d.Wo && o < d.Co;
             const int oc = ok ? o : 0;
-            float v = acc[mt][r];
-            const float bb = bp[oc];
-            v += has_bias ? bb : 0.f;
+            float v = acc[mt][r] + bias_s[ol];
             v = v > 0.f ? v : v * neg;
             if (ok) p.out[((size_t)b * d.Co + oc) * hw + pix] = v;
         }
     }
+    DSTAMP(30);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -191,7 +244,7 @@ size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C) {
 template <int TH, int MT>
 static int launch_dcn_fwd2(const DcnFwdParams& p, const bf16x8* wpack, hipStream_t st) {
     constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
-    const size_t lds = (size_t)16 * (4 * TR * TC + 2 * 9 * 2 * MT * 32);
+    const size_t lds = (size_t)16 * (4 * TR * TC + 2 * 9 * 2 * MT * 32) + sizeof(float) * MT * 32;
     auto k = dcn_fwd2_kernel<TH, MT>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd2: cannot reserve %zu B of LDS", lds);
     const DcnGeom& d = p.d;
@@ -310,20 +363,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
 #pragma unroll 4
             for (int e = tid; e < 5 * WBLK; e += NT) wsb[e] = src[e];
         }
-        for (int it = tid; it < 4 * NPOS; it += NT) {
-            const int quad = it / NPOS, pos = it - quad * NPOS;
-            const int r = pos / TC, s = pos - r * TC;
-            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
-                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
-                v.x = src[0];
-                if (cb + 1 < d.C) v.y = src[HW];
-                if (cb + 2 < d.C) v.z = src[2 * HW];
-                if (cb + 3 < d.C) v.w = src[3 * HW];
-            }
-            xt[it] = v;
-        }
+        stage_x_tile<NT, 4, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
         __syncthreads();
 
 #pragma unroll 1
@@ -548,33 +588,36 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
             const int o = mb * 64 + ol;
             gT[px * GP + ol] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
         }
-        for (int it = tid; it < 2 * NPOS; it += NT) {
-            const int quad = it / NPOS, pos = it - quad * NPOS;
-            const int r = pos / TC, s = pos - r * TC;
-            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
-                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
-                v.x = src[0];
-                if (cb + 1 < d.C) v.y = src[HW];
-                if (cb + 2 < d.C) v.z = src[2 * HW];
-                if (cb + 3 < d.C) v.w = src[3 * HW];
-            }
-            xt[it] = v;
-        }
+        stage_x_tile<NT, 2, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
         __syncthreads();
-        // column tile: item = (pixel, tap); 8 channels of the chunk share the sampling geometry
-        for (int it = tid; it < DCN_NPX * 9; it += NT) {
+        // column tile: item = (pixel, tap); 8 channels of the chunk share the sampling geometry.
+        // (dy, dx, mask) of all of a thread's items are fetched first, unconditionally (clamped pixel).
+        constexpr int NBI = (DCN_NPX * 9 + NT - 1) / NT;
+        float b_dy[NBI], b_dx[NBI], b_m[NBI];
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int it_raw = tid + i * NT;
+            const int it = it_raw < DCN_NPX * 9 ? it_raw : 0;
+            const int px = it & 127, tap = it >> 7;
+            const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+            const size_t pixc = (oy < d.Ho && ox < d.Wo) ? (size_t)oy * d.Wo + ox : 0;
+            const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * tap) * hw + pixc;
+            b_dy[i] = offp[0];
+            b_dx[i] = offp[hw];
+            b_m[i] = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + tap) * hw + pixc];
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int it = tid + i * NT;
+            if (it >= DCN_NPX * 9) continue;
             const int px = it & 127, tap = it >> 7;
             const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if (oy < d.Ho && ox < d.Wo) {
-                const size_t pix = (size_t)oy * d.Wo + ox;
-                const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * tap) * hw + pix;
-                const float dy = offp[0], dx = offp[hw];
-                float m = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + tap) * hw + pix];
+                const float dy = b_dy[i], dx = b_dx[i];
+                float m = b_m[i];
                 if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
                 const float y = (float)(oy * d.stride - d.pad + (tap / 3) * d.dil) + dy;
                 const float x = (float)(ox * d.stride - d.pad + (tap % 3) * d.dil) + dx;
@@ -772,31 +815,30 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * 8;
         const int g = c0 / d.cpg;
+        // the 9 taps' (dy, dx, mask) of this lane's pixel for the chunk's deformable group: 27 unconditional loads
+        // issued before the staging below, so their latency is paid once per chunk instead of once per tap
+        float o_dy[9], o_dx[9], o_m[9];
+        {
+            const size_t pixc = px_ok ? pix : 0;
+            const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pixc;
+            const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pixc;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                o_dy[t9] = offp[(size_t)(2 * t9) * hw];
+                o_dx[t9] = offp[(size_t)(2 * t9 + 1) * hw];
+                o_m[t9] = mskp[(size_t)t9 * hw];
+            }
+        }
         {
             const bf16x8* src = wpack + (size_t)chunk * 3 * WBLK;
 #pragma unroll 3
             for (int e = tid; e < 3 * WBLK; e += NT) wsb[e] = src[e];
         }
-        for (int it = tid; it < 2 * NPOS; it += NT) {
-            const int quad = it / NPOS, pos = it - quad * NPOS;
-            const int r = pos / TC, s = pos - r * TC;
-            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C) {
-                const float* src = d.x + ((size_t)b * d.C + cb) * HW + (size_t)gy * d.W + gx;
-                v.x = src[0];
-                if (cb + 1 < d.C) v.y = src[HW];
-                if (cb + 2 < d.C) v.z = src[2 * HW];
-                if (cb + 3 < d.C) v.w = src[3 * HW];
-            }
-            xt[it] = v;
-        }
+        stage_x_tile<NT, 2, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
         __syncthreads();
 
         const int cq = c0 + 4 * hi;  // this lane's first channel
-        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pix;
-        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pix;
-#pragma unroll 1
+#pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
             f32x16 acc = zero16();
             const bf16x8* wb_hi = wsb + mt * WBLK;
@@ -818,8 +860,8 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                 int r0 = 0, r1 = 0, s0 = 0, s1 = 0, cy0 = 0, cy1 = 0, cx0 = 0, cx1 = 0;
                 float t[4] = {0.f, 0.f, 0.f, 0.f};
                 if (px_ok) {
-                    const float dy = offp[(size_t)(2 * tap) * hw], dx = offp[(size_t)(2 * tap + 1) * hw];
-                    m = mskp[(size_t)tap * hw];
+                    const float dy = o_dy[tap], dx = o_dx[tap];
+                    m = o_m[tap];
                     if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
                     const float y = (float)(oy - d.pad + tap / 3) + dy;
                     const float x = (float)(ox - d.pad + tap % 3) + dx;
