@@ -219,6 +219,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     nl, kms, kbytes = timer.result()
+    # HBM traffic of the DCN forward kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 runs,
+    # profiles/r01_dcn_fwd_pmc.json): measured bytes per output pixel x the pixels an average timed launch covers
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_dcn_fwd_pmc.json')) as f:
+            pmc = json.load(f)
+        if args.nf == 64 and nl > 0:
+            traffic = round(pmc['hbm_bytes_per_pixel'] * (kbytes / nl) / pmc['algorithmic_bytes_per_pixel'])
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         line = {
@@ -245,7 +255,7 @@ def main():
                          'achieved': round(kbytes / (kms * 1e-3) / 1e9, 2) if kms > 0 else None,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
-                         'traffic': None, 'launches': nl, 'avg_launch_ms': round(kms / max(nl, 1), 4),
+                         'traffic': traffic, 'launches': nl, 'avg_launch_ms': round(kms / max(nl, 1), 4),
                          'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
