@@ -753,20 +753,31 @@ __global__ void pack_weights_bwd3_kernel(const float* __restrict__ w, bf16x8* __
     }
 }
 
-// add `c` to priv[idx] (float4) with intra-wave collision handling; `pend` = this lane has work
-__device__ __forceinline__ void claim_add(volatile int* claim, volatile float* priv, int idx, float4 c, bool pend, int lane) {
-    while (__any(pend)) {
-        if (pend) claim[idx] = lane;
+// Add c[k] to priv4[idx[k]] for the four bilinear corners of one sample, with intra-wave collision handling:
+// every pending (lane, corner) writes its id to the cell's claim word, reads it back, and the winners do a plain
+// 128-bit read-modify-write; losers (another lane or corner hit the same cell in this round) retry.  One LDS round
+// trip per round for all four corners; one round in the common collision-free case.  LDS operations of a wave are
+// executed in program order, so the read-back sees the last claim written in this round.
+__device__ __forceinline__ void claim_add4(volatile int* claim, float4* priv4, const int (&idx)[4], const float4 (&c)[4],
+                                           bool p0, bool p1, bool p2, bool p3, int lane) {
+    bool pend[4] = {p0, p1, p2, p3};
+    while (__any(pend[0] || pend[1] || pend[2] || pend[3])) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (pend[k]) claim[idx[k]] = lane * 4 + k;
         asm volatile("" ::: "memory");
-        const bool win = pend && claim[idx] == lane;
-        if (win) {
-            volatile float* q = priv + 4 * idx;
-            const float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-            q[0] = a0 + c.x;
-            q[1] = a1 + c.y;
-            q[2] = a2 + c.z;
-            q[3] = a3 + c.w;
-            pend = false;
+        int got[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) got[k] = pend[k] ? claim[idx[k]] : -1;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (got[k] == lane * 4 + k) {
+                float4 v = priv4[idx[k]];
+                v.x += c[k].x; v.y += c[k].y; v.z += c[k].z; v.w += c[k].w;
+                priv4[idx[k]] = v;
+                pend[k] = false;
+            }
         }
         asm volatile("" ::: "memory");
     }
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     const bool px_ok = oy < d.Ho && ox < d.Wo;
     const size_t pix = (size_t)oy * d.Wo + ox;
     const float4* xq = xt + hi * NPOS;                       // this lane's channel quad in the shared x tile
-    volatile float* myp = reinterpret_cast<volatile float*>(priv + (wave * 2 + hi) * PPOS);
+    float4* myp = priv + (wave * 2 + hi) * PPOS;
     volatile int* myc = claim + (wave * 2 + hi) * PPOS;
 
     bf16x8 gh[NK], gl[NK];
@@ -915,10 +926,12 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                 {
                     const int pr0 = r0 - wave, pr1 = r1 - wave;
                     const bool go = inside && in_win;
-                    claim_add(myc, myp, pr0 * TC + s0, make_float4(w00 * t[0], w00 * t[1], w00 * t[2], w00 * t[3]), go && w00 != 0.f, lane);
-                    claim_add(myc, myp, pr0 * TC + s1, make_float4(w01 * t[0], w01 * t[1], w01 * t[2], w01 * t[3]), go && w01 != 0.f, lane);
-                    claim_add(myc, myp, pr1 * TC + s0, make_float4(w10 * t[0], w10 * t[1], w10 * t[2], w10 * t[3]), go && w10 != 0.f, lane);
-                    claim_add(myc, myp, pr1 * TC + s1, make_float4(w11 * t[0], w11 * t[1], w11 * t[2], w11 * t[3]), go && w11 != 0.f, lane);
+                    const int cidx[4] = {go ? pr0 * TC + s0 : 0, go ? pr0 * TC + s1 : 0, go ? pr1 * TC + s0 : 0, go ? pr1 * TC + s1 : 0};
+                    const float4 cval[4] = {make_float4(w00 * t[0], w00 * t[1], w00 * t[2], w00 * t[3]),
+                                            make_float4(w01 * t[0], w01 * t[1], w01 * t[2], w01 * t[3]),
+                                            make_float4(w10 * t[0], w10 * t[1], w10 * t[2], w10 * t[3]),
+                                            make_float4(w11 * t[0], w11 * t[1], w11 * t[2], w11 * t[3])};
+                    claim_add4(myc, myp, cidx, cval, go && w00 != 0.f, go && w01 != 0.f, go && w10 != 0.f, go && w11 != 0.f, lane);
                     if (inside && !in_win) {  // large offset: straight to global memory
                         float* gp = p.gx + ((size_t)b * d.C + cq) * HW;
                         const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
