@@ -15,6 +15,30 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     }
 }
 
+// 4x4 transpose inside every quad of lanes: on entry lane j (= lane & 3) holds r[i] = M[i][j]; on exit it holds
+// r[i] = M[j][i].  Two butterfly stages over DPP quad_perm (lane ^ 1, lane ^ 2): 12 VALU ops per block.  Used to turn
+// the MFMA D layout (lane = pixel column, registers = 4 consecutive channels) into "lane = channel, registers = 4
+// consecutive pixels", so the epilogue can issue 16-byte stores (dword stores are store-issue-bound: ~3.5 B/clk/CU).
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2, float& r3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    {   // stage 1: exchange across lane ^ 1 within register pairs (0,1) and (2,3)
+        const float x01 = b0 ? r0 : r1, y01 = dpp_xor1(x01);
+        const float x23 = b0 ? r2 : r3, y23 = dpp_xor1(x23);
+        if (b0) { r0 = y01; r2 = y23; } else { r1 = y01; r3 = y23; }
+    }
+    {   // stage 2: exchange across lane ^ 2 within register pairs (0,2) and (1,3)
+        const float x02 = b1 ? r0 : r2, y02 = dpp_xor2(x02);
+        const float x13 = b1 ? r1 : r3, y13 = dpp_xor2(x13);
+        if (b1) { r0 = y02; r1 = y13; } else { r2 = y02; r3 = y13; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // packed[mb][chunk][part][tap][oc][m][8]: part 0 = hi, 1 = lo; oc < 2*CCG octets of the chunk;
 // m < MP rows of m-block mb.   mode 0: A[o][(tap,c)] = w[o][c][tap]  (w: [Co][Ctot][T])

@@ -79,6 +79,49 @@ __device__ __forceinline__ void conv2_epilogue(f32x16 (&acc)[MT][2], const ConvF
     }
 }
 
+// 16-byte-store epilogue for the plain / residual cases (MODE 0 / 1) when Wout % 4 == 0 and the output (and residual)
+// base pointers are 16-byte aligned: each 4-register group (4 consecutive channels x this lane's pixel) is transposed
+// inside the lane quad, after which lane j holds channel j of the group at 4 consecutive pixels.
+template <int MT, int MODE>
+__device__ __forceinline__ void conv2_epilogue_v4(f32x16 (&acc)[MT][2], const ConvFwdParams& p, const float* bias_s, int b,
+                                                  int o0, int row0, int x0, int lo, int hi) {
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+    const int j = lo & 3, col4 = x0 + (lo & ~3);  // this lane's channel-in-group and first pixel column after the transpose
+    const bool col_ok = col4 < p.Wout;            // Wout % 4 == 0: the float4 is entirely inside or outside
+    const size_t HW = (size_t)p.Hout * p.Wout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = row0 + n;
+        if (row >= p.Hout) continue;  // wave-uniform
+        const size_t pix = (size_t)row * p.Wout + col4;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float4 resv[4];
+            if (MODE == 1) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int o = o0 + m * 32 + 8 * rg + 4 * hi + j;
+                    const bool ok = col_ok && o < p.Co;
+                    resv[rg] = *reinterpret_cast<const float4*>(p.res + (ok ? ((size_t)b * p.Co + o) * HW + pix : 0));
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float r0 = acc[m][n][4 * rg + 0], r1 = acc[m][n][4 * rg + 1], r2 = acc[m][n][4 * rg + 2], r3 = acc[m][n][4 * rg + 3];
+                quad_transpose4(r0, r1, r2, r3, lo);
+                const int ol = m * 32 + 8 * rg + 4 * hi + j;
+                const int o = o0 + ol;
+                const float bb = bias_s[ol];
+                float4 v = make_float4(r0 + bb, r1 + bb, r2 + bb, r3 + bb);
+                v.x = v.x > 0.f ? v.x : v.x * neg; v.y = v.y > 0.f ? v.y : v.y * neg;
+                v.z = v.z > 0.f ? v.z : v.z * neg; v.w = v.w > 0.f ? v.w : v.w * neg;
+                if (MODE == 1) { v.x += resv[rg].x; v.y += resv[rg].y; v.z += resv[rg].z; v.w += resv[rg].w; }
+                if (col_ok && o < p.Co) *reinterpret_cast<float4*>(p.out1 + ((size_t)b * p.Co + o) * HW + pix) = v;
+            }
+        }
+    }
+}
+
 template <int KS, int STRIDE, int MT, int CCG, bool ACT_IN, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdParams p) {
     constexpr int T = KS * KS, PAD = KS / 2, TH = 2 * NW, TW = 32, NTHR = NW * 64;
@@ -232,11 +275,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
             acc[m][1] = zero16();
         }
         const int cx0 = x0, cy0 = y0, cmb = mb, cb_ = b;
+        STAMP(0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (!PF) issue_loads(chunk);
             commit_to_lds(chunk);
+            STAMP(1 + chunk * 5);
             __syncthreads();
+            STAMP(2 + chunk * 5);
             if (PF && chunk + 1 < nchunks) issue_loads(chunk + 1);
+            STAMP(3 + chunk * 5);
 #pragma unroll
             for (int tap = 0; tap < T; ++tap) {
                 const int dy = tap / KS, dx = tap % KS;
@@ -269,20 +316,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
                         for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[m], bh[n], acc[m][n]);
                 }
             }
+            STAMP(4 + chunk * 5);
             __syncthreads();
+            STAMP(5 + chunk * 5);
         }
         if (p.ps)
             conv2_epilogue<MT, 3>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
         else if (p.out2 != nullptr)
             conv2_epilogue<MT, 2>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
-        else if (p.res != nullptr)
-            conv2_epilogue<MT, 1>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
-        else
-            conv2_epilogue<MT, 0>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        else if (p.res != nullptr) {
+            if (p.vec4) conv2_epilogue_v4<MT, 1>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0, lo, hi);
+            else conv2_epilogue<MT, 1>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        } else {
+            if (p.vec4) conv2_epilogue_v4<MT, 0>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0, lo, hi);
+            else conv2_epilogue<MT, 0>(acc, p, bias_s, cb_, cmb * MP, cy0 + wave * 2, cx0 + lo, hi);
+        }
+        STAMP(30);
         if (S + nwq < range1) {  // the stores above are asynchronous: the next tile's loads go out right behind them
             decode(S + nwq);
             if (PF) issue_loads(0);
         }
+        STAMP(31);
         // bias_s of this tile is read by the epilogue above and rewritten by the next tile's chunk-0 commit:
         // that commit is followed by a barrier before any MFMA, and every wave passed the last barrier of this
         // tile before its epilogue; a wave still in its epilogue while another already commits the next tile
@@ -340,6 +394,7 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
                        Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode);
     p.wpack = workspace;
     p.swz = rvsr_swizzle_enabled();
+    p.vec4 = (p.Wout % 4 == 0) && ((((uintptr_t)p.out1) | ((uintptr_t)p.res)) & 15) == 0 && !p.ps && p.out2 == nullptr;
 #define DISPATCH2(KS, S, CCG)                                   \
     do {                                                        \
         if (mt == 1) return launch_fwd2<KS, S, 1, CCG>(p, st);  \

@@ -8,6 +8,7 @@ struct ConvFwdParams {
     const float* w;
     const void* wpack;  // bf16x3 path: packed weights (conv2_kernels.hip)
     int swz;            // XCD-aware workgroup remap on/off
+    int vec4;           // 16-byte-store epilogue usable (Wout % 4 == 0, aligned pointers)
     const float* bias;
     const float* res;
     float* out1;
