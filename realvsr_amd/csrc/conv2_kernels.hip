@@ -502,6 +502,44 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     float4 gv[NGI][NGV], sv[ACT ? NGI : 1][NGV], xv[NXI][2];
     unsigned gok = 0, xok = 0;              // bit (i * 4 + k): float4 k of item i is inside the image
 
+    // per-thread item geometry is tile-independent: decode it once (the divisions / 64-bit products used to cost more
+    // than the loads themselves: ~5.5 K cycles to issue 20 loads)
+    int g_row[NGI], g_gx8[NGI], g_o[NGI], g_lds[NGI];
+    unsigned g_const[NGI];
+#pragma unroll
+    for (int i = 0; i < NGI; ++i) {
+        const int it = tid + i * WG2_THREADS;
+        const int q = it & 3, row = (it >> 2) & 3, ol = it >> 4;
+        g_row[i] = row;
+        g_gx8[i] = 8 * q;
+        g_o[i] = mb * 64 + ol;
+        g_lds[i] = ol * WG2_GP + row * 64 + q * 16;
+        const int o = g_o[i] < p.Co ? g_o[i] : 0;
+        g_const[i] = GMODE == 0 ? (unsigned)((o * H + row) * W + 8 * q)
+                                : (unsigned)((((o >> 2) * 2 * H) + 2 * row + ((o >> 1) & 1)) * (2 * W) + 16 * q);
+    }
+    int x_row[NXI], x_gx[NXI], x_lds[NXI];
+    unsigned x_const[NXI];
+    bool x_live[NXI], x_sec[NXI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+        const int it_raw = tid + i * WG2_THREADS;
+        const bool live = it_raw < 64 * 30;
+        const int it = live ? it_raw : 0;
+        const int cl = it / 30, rem = it - cl * 30;
+        const int row = rem / 5, q = rem - row * 5;
+        const int c = c0 + cl;
+        x_live[i] = live && c < Ctot;
+        x_sec[i] = x_live[i] && c >= C1;
+        x_row[i] = row - 1;
+        x_gx[i] = 8 * q - 4;
+        x_lds[i] = live ? cl * WG2_XP + row * 80 + q * 16 : -1;
+        const int cc = x_live[i] ? (x_sec[i] ? c - C1 : c) : 0;
+        x_const[i] = (unsigned)(cc * H * W);
+    }
+    const size_t img_g = GMODE == 0 ? (size_t)p.Co * H * W : (size_t)p.Co * H * W;  // elements per image of G (same count either way)
+    const size_t img_x1 = (size_t)C1 * H * W, img_x2 = (size_t)(Ctot - C1) * H * W;
+
     auto issue_loads = [&](int tile) {
         const int b = tile / (p.nty * p.ntx);
         const int trem = tile - b * (p.nty * p.ntx);
@@ -509,52 +547,48 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         const int y0 = ty * 4, x0 = tx * 32;
         gok = 0;
         xok = 0;
+        const float* gimg = p.g.p + (size_t)b * img_g;
+        const float* simg = ACT ? p.g.act + (size_t)b * img_g : nullptr;
 #pragma unroll
         for (int i = 0; i < NGI; ++i) {
-            const int it = tid + i * WG2_THREADS;
-            const int q = it & 3, row = (it >> 2) & 3, ol = it >> 4;
-            const int o = mb * 64 + ol, gy = y0 + row, gx = x0 + 8 * q;
-            const bool ok = o < p.Co && gy < H;
+            const int gy = y0 + g_row[i], gx = x0 + g_gx8[i];
+            const bool ok = g_o[i] < p.Co && gy < H;
             if (GMODE == 0) {
-                const size_t base = ok ? (((size_t)b * p.Co + o) * H + gy) * W : 0;
+                const unsigned base = g_const[i] + (unsigned)(y0 * W + x0);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bool okk = ok && gx + 4 * k < W;
-                    const size_t idx = okk ? base + gx + 4 * k : 0;
-                    gv[i][k] = *reinterpret_cast<const float4*>(p.g.p + idx);
-                    if (ACT) sv[i][k] = *reinterpret_cast<const float4*>(p.g.act + idx);
-                    gok |= (okk ? 1u : 0u) << (i * 4 + k);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bool okk = ok && gx + 4 * kk < W;
+                    const unsigned idx = okk ? base + 4 * kk : 0;
+                    gv[i][kk] = *reinterpret_cast<const float4*>(gimg + idx);
+                    if (ACT) sv[i][kk] = *reinterpret_cast<const float4*>(simg + idx);
+                    gok |= (okk ? 1u : 0u) << (i * 4 + kk);
                 }
-            } else {  // stored (Co/4, 2H, 2W) pixel-shuffled: 8 virtual px = 16 stored floats, every other one
-                const size_t base = ok ? (((size_t)b * (p.Co >> 2) + (o >> 2)) * (2 * H) + 2 * gy + ((o >> 1) & 1)) * (size_t)(2 * W) : 0;
+            } else {
+                const unsigned base = g_const[i] + (unsigned)(2 * y0 * 2 * W + 2 * x0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool okk = ok && gx + 2 * k < W;
-                    const size_t idx = okk ? base + 2 * gx + 4 * k : 0;
-                    gv[i][k] = *reinterpret_cast<const float4*>(p.g.p + idx);
-                    if (ACT) sv[i][k] = *reinterpret_cast<const float4*>(p.g.act + idx);
-                    gok |= (okk ? 1u : 0u) << (i * 4 + k);
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bool okk = ok && gx + 2 * kk < W;
+                    const unsigned idx = okk ? base + 4 * kk : 0;
+                    gv[i][kk] = *reinterpret_cast<const float4*>(gimg + idx);
+                    if (ACT) sv[i][kk] = *reinterpret_cast<const float4*>(simg + idx);
+                    gok |= (okk ? 1u : 0u) << (i * 4 + kk);
                 }
             }
         }
+        const float* x1img = p.x.a.p + (size_t)b * img_x1;
+        const float* x2img = p.x.b.p != nullptr ? p.x.b.p + (size_t)b * img_x2 : x1img;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
-            const int it_raw = tid + i * WG2_THREADS;
-            const bool live = it_raw < 64 * 30;
-            const int it = live ? it_raw : 0;
-            const int cl = it / 30, rem = it - cl * 30;
-            const int row = rem / 5, q = rem - row * 5;
-            const int c = c0 + cl, gy = y0 - 1 + row, gx = x0 - 4 + 8 * q;
-            const bool ok = live && c < Ctot && gy >= 0 && gy < H;
-            const bool sec = ok && c >= C1;
-            const float* src = sec ? p.x.b.p : p.x.a.p;
-            const size_t base = ok ? (((size_t)b * (sec ? Ctot - C1 : C1) + (sec ? c - C1 : c)) * H + gy) * W : 0;
+            const int gy = y0 + x_row[i], gx = x0 + x_gx[i];
+            const bool ok = x_live[i] && gy >= 0 && gy < H;
+            const float* src = x_sec[i] ? x2img : x1img;
+            const unsigned base = x_const[i] + (unsigned)((ok ? gy : 0) * W);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int gxx = gx + 4 * k;
+            for (int kk = 0; kk < 2; ++kk) {
+                const int gxx = gx + 4 * kk;
                 const bool okk = ok && gxx >= 0 && gxx < W;
-                xv[i][k] = *reinterpret_cast<const float4*>(src + (okk ? base + gxx : 0));
-                xok |= (okk ? 1u : 0u) << (i * 4 + k);
+                xv[i][kk] = *reinterpret_cast<const float4*>(src + (okk ? base + gxx : 0));
+                xok |= (okk ? 1u : 0u) << (i * 4 + kk);
             }
         }
     };
@@ -562,8 +596,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < NGI; ++i) {
-            const int it = tid + i * WG2_THREADS;
-            const int q = it & 3, row = (it >> 2) & 3, ol = it >> 4;
+            const int ol = g_o[i] - mb * 64;
             float v[8];
             if (GMODE == 0) {
 #pragma unroll
@@ -600,16 +633,12 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             }
             bf16x8 h8, l8;
             split8(v, h8, l8);
-            const int off = ol * WG2_GP + row * 64 + q * 16;
-            *reinterpret_cast<bf16x8*>(gs_hi + off) = h8;
-            *reinterpret_cast<bf16x8*>(gs_lo + off) = l8;
+            *reinterpret_cast<bf16x8*>(gs_hi + g_lds[i]) = h8;
+            *reinterpret_cast<bf16x8*>(gs_lo + g_lds[i]) = l8;
         }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
-            const int it = tid + i * WG2_THREADS;
-            if (it >= 64 * 30) continue;
-            const int cl = it / 30, rem = it - cl * 30;
-            const int row = rem / 5, q = rem - row * 5;
+            if (x_lds[i] < 0) continue;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -620,9 +649,8 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             }
             bf16x8 h8, l8;
             split8(v, h8, l8);
-            const int off = cl * WG2_XP + row * 80 + q * 16;
-            *reinterpret_cast<bf16x8*>(xs_hi + off) = h8;
-            *reinterpret_cast<bf16x8*>(xs_lo + off) = l8;
+            *reinterpret_cast<bf16x8*>(xs_hi + x_lds[i]) = h8;
+            *reinterpret_cast<bf16x8*>(xs_lo + x_lds[i]) = l8;
         }
     };
 
@@ -632,9 +660,14 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
     if (t_begin < t_end) issue_loads(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
+        const int ti = tile - t_begin;
+        if (ti < 6) STAMP(100 + ti * 5);
         commit();
+        if (ti < 6) STAMP(101 + ti * 5);
         __syncthreads();
+        if (ti < 6) STAMP(102 + ti * 5);
         if (tile + 1 < t_end) issue_loads(tile + 1);
+        if (ti < 6) STAMP(103 + ti * 5);
         if (m_live) {
 #pragma unroll 2
             for (int ks = 0; ks < 8; ++ks) {
@@ -653,6 +686,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                 }
             }
         }
+        if (ti < 6) STAMP(104 + ti * 5);
         __syncthreads();
     }
 
