@@ -7,7 +7,8 @@ barrier + torch.cuda.synchronize() on both sides; max over ranks; rank 0 prints 
 
 Workload = BASELINE.json configs[1] ("EDVR-M 64ch, 5-frame 180x320 LR, batch 8, fwd+bwd on
 1xMI355X"): EDVR(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, w_TSA=True), x4 output,
-loss = LapPyrLoss(3,'cb','cb') on Y + Charbonnier on CbCr, Adam.  Synthetic data:
+loss = LapPyrLoss(3,'cb','cb') on Y + GWLoss(w=4) on CbCr (the composition of the reference's
+optimize_parameters, VideoSR_AllPair_model_YCbCr_Split.py:163-191, with the in-tree 'cb' low-frequency term), Adam.  Synthetic data:
 x ~ U[0,1) seed 1234, GT ~ U[0,1) seed 1235, default module init under seed 0 with
 conv_offset_mask.weight ~ N(0, 0.01^2) so the deformable offsets are non-zero.  Weak scaling:
 every rank processes its own B=8 windows; value = N*B*K / time.
@@ -132,7 +133,7 @@ def cpu_baseline(nf, nframes, back_RBs, H, W):
     gt = torch.rand(1, 3, 4 * H, 4 * W, generator=torch.Generator().manual_seed(1235))
     t0 = time.perf_counter()
     out = O.edvr_forward(sd, x, nframes=nframes, groups=8, front_RBs=5, back_RBs=back_RBs, w_TSA=True)
-    loss = O.lap_pyr_loss(out[:, 0:1], gt[:, 0:1], 3) + O.charbonnier(out[:, 1:3], gt[:, 1:3])
+    loss = O.lap_pyr_loss(out[:, 0:1], gt[:, 0:1], 3) + O.gw_loss(out[:, 1:3], gt[:, 1:3], 4)
     loss.backward()
     dt = time.perf_counter() - t0
     return {'value': round(1.0 / dt, 5), 'unit': 'HR frames/s', 'cores': cores, 'kind': 'port',
@@ -184,7 +185,7 @@ def main():
     B, N, H, W = args.batch, args.nframes, args.height, args.width
     net = build_net(args.nf, N, args.back_rbs, device)
     x, gt = make_batch(B, N, H, W, device, rank)
-    crit_y, crit_c = L.LapPyrLoss(3, 'cb', 'cb', 'mean'), L.CharbonnierLoss()
+    crit_y, crit_c = L.LapPyrLoss(3, 'cb', 'cb', 'mean'), L.GWLoss(w=4)
     reducer = BucketedGradAllReduce(net.parameters(), bucket_mb=4.0)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.99))
 
@@ -245,7 +246,7 @@ def main():
             'dtype': 'f32',  # tensors, accumulation and all non-GEMM math are f32; see config.gemm for the GEMM operands
             'data': 'synthetic',
             'config': {'workload': 'EDVR-M nf%d, %d-frame %dx%d LR windows, batch %d per GPU, x4 output, '
-                                   'fwd + LapPyr(cb,cb)/Charbonnier loss + bwd + Adam step'
+                                   'fwd + LapPyr(cb,cb) on Y + GWLoss on CbCr + bwd + Adam step'
                                    % (args.nf, N, H, W, B),
                        'per_gpu_batch': B, 'global_batch': world * B, 'parallelism': 'sequence-dp%d' % world,
                        'gemm': gemm_mode + (' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)'

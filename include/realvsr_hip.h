@@ -194,6 +194,14 @@ int rvsr_charbonnier_forward(const float* x, const float* y, size_t n, float eps
 int rvsr_charbonnier_backward(const float* x, const float* y, const float* gscalar, float scale, float eps,
                               float* gx, size_t n, void* stream);
 
+/* GWLoss (codes/models/loss.py:54-80): out[0] = scale * sum (1 + w|Sx(d)|)(1 + w|Sy(d)|)|d|, d = x1 - x2, depthwise 3x3 Sobel
+ * with zero padding.  fa/fbx/fby (NULL together, or three buffers shaped like x1) receive the per-pixel factors the
+ * backward needs.  workspace: rvsr_charbonnier_workspace_bytes().  backward: gx1 = gscalar[0]*scale * dL/dx1 (dL/dx2 = -gx1). */
+int rvsr_gwloss_forward(const float* x1, const float* x2, size_t planes, int H, int W, float w, double scale, float* out,
+                        float* fa, float* fbx, float* fby, void* workspace, void* stream);
+int rvsr_gwloss_backward(const float* fa, const float* fbx, const float* fby, const float* gscalar, float scale, float* gx,
+                         size_t planes, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

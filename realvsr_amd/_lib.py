@@ -48,6 +48,8 @@ SIGNATURES = {
     'rvsr_charbonnier_workspace_bytes': (c_size, []),
     'rvsr_charbonnier_forward': (c_int, [c_fp, c_fp, c_size, c_float, c_double, c_fp, c_fp, c_fp]),
     'rvsr_charbonnier_backward': (c_int, [c_fp, c_fp, c_fp, c_float, c_float, c_fp, c_size, c_fp]),
+    'rvsr_gwloss_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'rvsr_gwloss_backward': (c_int, [c_fp, c_fp, c_fp, c_fp, c_float, c_fp, c_size, c_int, c_int, c_fp]),
 }
 
 

@@ -490,3 +490,94 @@ extern "C" int rvsr_charbonnier_backward(const float* x, const float* y, const f
     hipLaunchKernelGGL(charb_bwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, x, y, gscalar, scale, eps, gx, n);
     CHECK_LAUNCH("charbonnier_bwd");
 }
+
+// ---------------------------------------------------------------- Gradient-weighted loss (GWLoss)
+// codes/models/loss.py:54-80: L = (1 + w|Sx(x1) - Sx(x2)|) (1 + w|Sy(x1) - Sy(x2)|) |x1 - x2| with depthwise 3x3 Sobel
+// filters and zero padding.  Sobel is linear, so only d = x1 - x2 is filtered.  One fused pass: 3x3 window of d,
+// loss term, block-reduced sum; when a gradient is wanted it also stores the three per-pixel factors the backward
+// gather needs (A = dL/dd through |d|, Bx / By = dL/dSx, dL/dSy).
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void gw_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ x2, size_t planes, int H, int W, float w,
+                              double* __restrict__ partial, float* __restrict__ fa, float* __restrict__ fbx,
+                              float* __restrict__ fby) {
+    __shared__ double red[256];
+    const size_t n = planes * H * W;
+    double acc = 0.0;
+    LOOP(i, n) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const size_t base = i - (size_t)y * W - x;
+        float d[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int yy = y + a - 1, xx = x + b - 1;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const size_t j = in ? base + (size_t)yy * W + xx : i;
+                const float v = x1[j] - x2[j];
+                d[a][b] = in ? v : 0.f;
+            }
+        const float sx = (d[0][2] - d[0][0]) + 2.f * (d[1][2] - d[1][0]) + (d[2][2] - d[2][0]);
+        const float sy = (d[2][0] - d[0][0]) + 2.f * (d[2][1] - d[0][1]) + (d[2][2] - d[0][2]);
+        const float ax = 1.f + w * fabsf(sx), ay = 1.f + w * fabsf(sy), ad = fabsf(d[1][1]);
+        acc += (double)(ax * ay * ad);
+        if (fa != nullptr) {
+            fa[i] = ax * ay * sgnf(d[1][1]);
+            fbx[i] = w * sgnf(sx) * ay * ad;
+            fby[i] = ax * w * sgnf(sy) * ad;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// g_d[q] = k * (A[q] + sum_p Bx[p] * kx[q - p] + By[p] * ky[q - p]),  Sx(d)_p = sum_{a,b} kx[a][b] d[p + (a-1, b-1)]
+__global__ void gw_bwd_kernel(const float* __restrict__ fa, const float* __restrict__ fbx, const float* __restrict__ fby,
+                              const float* __restrict__ gs, float scale, float* __restrict__ gx, size_t planes, int H, int W) {
+    const float k = gs[0] * scale;
+    const size_t n = planes * H * W;
+    LOOP(i, n) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const size_t base = i - (size_t)y * W - x;
+        float acc = fa[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                // p = q - (a-1, b-1) is the pixel whose filter tap (a, b) lands on q
+                const int yy = y - (a - 1), xx = x - (b - 1);
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const size_t j = base + (size_t)yy * W + xx;
+                const float kx = (b == 0 ? -1.f : (b == 2 ? 1.f : 0.f)) * (a == 1 ? 2.f : 1.f);
+                const float ky = (a == 0 ? -1.f : (a == 2 ? 1.f : 0.f)) * (b == 1 ? 2.f : 1.f);
+                acc += fbx[j] * kx + fby[j] * ky;
+            }
+        gx[i] = k * acc;
+    }
+}
+
+extern "C" int rvsr_gwloss_forward(const float* x1, const float* x2, size_t planes, int H, int W, float w, double scale,
+                                   float* out, float* fa, float* fbx, float* fby, void* workspace, void* stream) {
+    if (!x1 || !x2 || !out || !workspace) FAIL(RVSR_ERR_BAD_ARG, "gwloss: null argument");
+    if ((fa == nullptr) != (fbx == nullptr) || (fa == nullptr) != (fby == nullptr)) FAIL(RVSR_ERR_BAD_ARG, "gwloss: factor buffers must be given together");
+    const size_t n = planes * H * W;
+    unsigned nb = (unsigned)((n + 255) / 256);
+    if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(gw_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x1, x2, planes, H, W, w, (double*)workspace, fa, fbx, fby);
+    hipLaunchKernelGGL(charb_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, (int)nb, scale, out);
+    CHECK_LAUNCH("gwloss_fwd");
+}
+extern "C" int rvsr_gwloss_backward(const float* fa, const float* fbx, const float* fby, const float* gscalar, float scale,
+                                    float* gx, size_t planes, int H, int W, void* stream) {
+    if (!fa || !fbx || !fby || !gscalar || !gx) FAIL(RVSR_ERR_BAD_ARG, "gwloss backward: null argument");
+    const size_t n = planes * H * W;
+    hipLaunchKernelGGL(gw_bwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, fa, fbx, fby, gscalar, scale, gx, planes, H, W);
+    CHECK_LAUNCH("gwloss_bwd");
+}

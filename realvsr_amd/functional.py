@@ -445,3 +445,40 @@ class _Charbonnier(Function):
 
 def charbonnier(x, y, eps=1e-6, reduction='mean'):
     return _Charbonnier.apply(x, y, float(eps), reduction == 'mean')
+
+
+class _GWLoss(Function):
+    @staticmethod
+    def forward(ctx, x1, x2, w, mean):
+        _need_cuda(x1, x2)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, C, H, W = x1.shape
+        n = x1.numel()
+        out = x1.new_empty(())
+        L = _lib.lib()
+        ws = _workspace(L.rvsr_charbonnier_workspace_bytes(), x1.device)
+        scale = 1.0 / n if mean else 1.0
+        need = x1.requires_grad or x2.requires_grad
+        fac = x1.new_empty(3, B, C, H, W) if need else None
+        _lib.check(L.rvsr_gwloss_forward(_p(x1), _p(x2), B * C, H, W, float(w), scale, _p(out),
+                                         _p(fac[0]) if need else None, _p(fac[1]) if need else None,
+                                         _p(fac[2]) if need else None, _p(ws), _stream()), 'gwloss_forward')
+        ctx.cfg = (scale, B, C, H, W)
+        ctx.save_for_backward(fac)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (fac,) = ctx.saved_tensors
+        scale, B, C, H, W = ctx.cfg
+        g = g.contiguous()
+        gx = fac.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().rvsr_gwloss_backward(_p(fac[0]), _p(fac[1]), _p(fac[2]), _p(g), scale, _p(gx), B * C, H, W,
+                                                   _stream()), 'gwloss_backward')
+        return gx, (-gx if ctx.needs_input_grad[1] else None), None, None
+
+
+def gw_loss(x1, x2, w=4, reduction='mean'):
+    """Gradient-weighted loss (codes/models/loss.py:54-80), one fused pass."""
+    return _GWLoss.apply(x1, x2, float(w), reduction == 'mean')

@@ -23,6 +23,19 @@ class CharbonnierLoss(nn.Module):
         return RF.charbonnier(x, y, self.eps, 'mean' if self.reduction == 'mean' else 'sum')
 
 
+class GWLoss(nn.Module):
+    """Gradient Weighted Loss (codes/models/loss.py:54-80) -- the CbCr term of the reference's training loss
+    (VideoSR_AllPair_model_YCbCr_Split.py:184).  The Sobel filters are constants of the HIP kernel."""
+
+    def __init__(self, w=4, reduction='mean'):
+        super(GWLoss, self).__init__()
+        self.w = w
+        self.reduction = reduction
+
+    def forward(self, x1, x2):
+        return RF.gw_loss(x1, x2, self.w, 'mean' if self.reduction == 'mean' else 'sum')
+
+
 class PyramidLoss(nn.Module):
     """Pyramid Loss"""
 

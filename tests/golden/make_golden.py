@@ -191,7 +191,8 @@ def main():
                             ('pyr_gau_cb', loss_mod.PyramidLoss(3, 'gau', 'cb', 'mean')),
                             ('pyr_lap_l1', loss_mod.PyramidLoss(2, 'lap', 'l1', 'mean')),
                             ('pyr_gau_l2', loss_mod.PyramidLoss(3, 'gau', 'l2', 'mean')),
-                            ('cb', loss_mod.CharbonnierLoss())]:
+                            ('cb', loss_mod.CharbonnierLoss()), ('gw', loss_mod.GWLoss(w=4)),
+                            ('gw_sum', loss_mod.GWLoss(w=2, reduction='sum'))]:
             x.grad = None
             l = crit(x, y)
             l.backward()

@@ -92,7 +92,8 @@ def test_losses_fixture():
     g = load_golden('losses')
     crit = {'lappyr_cb': L.LapPyrLoss(3, 'cb', 'cb', 'mean'), 'lappyr_cb_sum': L.LapPyrLoss(2, 'cb', 'cb', 'sum'),
             'pyr_gau_cb': L.PyramidLoss(3, 'gau', 'cb', 'mean'), 'pyr_lap_l1': L.PyramidLoss(2, 'lap', 'l1', 'mean'),
-            'pyr_gau_l2': L.PyramidLoss(3, 'gau', 'l2', 'mean'), 'cb': L.CharbonnierLoss()}
+            'pyr_gau_l2': L.PyramidLoss(3, 'gau', 'l2', 'mean'), 'cb': L.CharbonnierLoss(), 'gw': L.GWLoss(w=4),
+            'gw_sum': L.GWLoss(w=2, reduction='sum')}
     for tag in ('y', 'rgb'):
         for name, fn in crit.items():
             x = torch.from_numpy(g['x_' + tag]).to(dev()).requires_grad_(True)
@@ -121,3 +122,28 @@ def test_pyramid_full_size_properties():
     z0 = torch.zeros_like(pa[0])
     rec0 = pa[0] + (z0 - RF.pyr_updiff(z0, rec1))
     check('collapse reconstructs the image', rec0, a, 1e-5)
+
+
+def test_hipgraph_capture_matches_eager():
+    """The whole forward is capturable in a hipGraph (BASELINE config 5 uses that): plain launches on the capturing
+    stream, no allocation / sync inside the operators once the workspace exists."""
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    d = dev()
+    torch.manual_seed(0)
+    net = EDVR(nf=16, nc=3, nframes=3, groups=2, front_RBs=1, back_RBs=1, w_TSA=True).to(d).eval()
+    x = torch.rand(1, 3, 3, 32, 48, device=d)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ref = net(x)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = net(x)
+        x.copy_(torch.rand(1, 3, 3, 32, 48, device=d))  # new frame window into the captured input buffer
+        graph.replay()
+        torch.cuda.synchronize()
+        ref2 = net(x)
+    assert not torch.equal(ref, ref2)
+    assert torch.equal(out, ref2)

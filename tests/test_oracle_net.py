@@ -104,7 +104,8 @@ def test_losses_fixture():
            'pyr_gau_cb': lambda x, y: O.pyramid_loss(x, y, 3, 'gau', 'cb'),
            'pyr_lap_l1': lambda x, y: O.pyramid_loss(x, y, 2, 'lap', 'l1'),
            'pyr_gau_l2': lambda x, y: O.pyramid_loss(x, y, 3, 'gau', 'l2'),
-           'cb': lambda x, y: O.charbonnier(x, y)}
+           'cb': lambda x, y: O.charbonnier(x, y), 'gw': lambda x, y: O.gw_loss(x, y, 4),
+           'gw_sum': lambda x, y: O.gw_loss(x, y, 2, 'sum')}
     for tag in ('y', 'rgb'):
         for name, fn in fns.items():
             x = _t(g, 'x_' + tag, True)
