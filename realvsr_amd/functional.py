@@ -458,7 +458,7 @@ class _GWLoss(Function):
         L = _lib.lib()
         ws = _workspace(L.rvsr_charbonnier_workspace_bytes(), x1.device)
         scale = 1.0 / n if mean else 1.0
-        need = x1.requires_grad or x2.requires_grad
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         fac = x1.new_empty(3, B, C, H, W) if need else None
         _lib.check(L.rvsr_gwloss_forward(_p(x1), _p(x2), B * C, H, W, float(w), scale, _p(out),
                                          _p(fac[0]) if need else None, _p(fac[1]) if need else None,
