@@ -70,23 +70,26 @@ struct TView {
     int mode;
 };
 
+// Branch-free on purpose: the address is clamped into the tensor and the load is ALWAYS issued, validity is applied
+// with a select afterwards.  A load inside a divergent `if` is waited for at the join by hipcc, which turns a
+// staging loop into one L2/HBM round trip per element (measured: 8 K cycles to "issue" 24 loads).
 __device__ __forceinline__ float tview_get(const TView& v, int b, int c, int y, int x) {
-    if (y < 0 || x < 0 || y >= v.Hv || x >= v.Wv) return 0.f;
+    bool ok = y >= 0 && x >= 0 && y < v.Hv && x < v.Wv && c >= 0 && c < v.C;
+    const int yc = ok ? y : 0, xc = ok ? x : 0, cc = ok ? c : 0;
     size_t idx;
-    if (v.mode == 0) {
-        idx = (((size_t)b * v.C + c) * v.Hs + y) * v.Ws + x;
+    if (v.mode == 0) {  // (uniform branches on the view mode)
+        idx = (((size_t)b * v.C + cc) * v.Hs + yc) * v.Ws + xc;
     } else if (v.mode == 1) {
-        if ((y | x) & 1) return 0.f;
-        const int ys = y >> 1, xs = x >> 1;
-        if (ys >= v.Hs || xs >= v.Ws) return 0.f;
-        idx = (((size_t)b * v.C + c) * v.Hs + ys) * v.Ws + xs;
+        const int ys = yc >> 1, xs = xc >> 1;
+        ok = ok && !((yc | xc) & 1) && ys < v.Hs && xs < v.Ws;
+        idx = (((size_t)b * v.C + cc) * v.Hs + (ys < v.Hs ? ys : 0)) * v.Ws + (xs < v.Ws ? xs : 0);
     } else {
-        const int cs = c >> 2, sy = (c >> 1) & 1, sx = c & 1;
-        idx = (((size_t)b * (v.C >> 2) + cs) * v.Hs + (2 * y + sy)) * v.Ws + (2 * x + sx);
+        const int cs = cc >> 2, sy = (cc >> 1) & 1, sx = cc & 1;
+        idx = (((size_t)b * (v.C >> 2) + cs) * v.Hs + (2 * yc + sy)) * v.Ws + (2 * xc + sx);
     }
     float val = v.p[idx];
     if (v.act != nullptr) val *= (v.act[idx] > 0.f ? 1.f : v.slope);
-    return val;
+    return ok ? val : 0.f;
 }
 
 // two views concatenated along channels (torch.cat([a, b], 1) without materialising it)
@@ -94,10 +97,10 @@ struct TCat {
     TView a, b;  // b.p == nullptr -> single input
 };
 __device__ __forceinline__ float tcat_get(const TCat& t, int bidx, int c, int y, int x) {
-    if (c < t.a.C) return tview_get(t.a, bidx, c, y, x);
-    c -= t.a.C;
-    if (t.b.p == nullptr || c >= t.b.C) return 0.f;
-    return tview_get(t.b, bidx, c, y, x);
+    if (t.b.p == nullptr) return tview_get(t.a, bidx, c, y, x);  // uniform
+    const float va = tview_get(t.a, bidx, c, y, x);              // 0 when c >= a.C
+    const float vb = tview_get(t.b, bidx, c - t.a.C, y, x);      // 0 when c < a.C
+    return c < t.a.C ? va : vb;
 }
 
 // ------------------------------------------------------------------------------------------
