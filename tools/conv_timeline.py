@@ -13,21 +13,32 @@ print('rc', L.rvsr_debug_read(buf))
 t = list(buf)
 names = {0: 'tile start'}
 V3 = os.environ.get('RVSR_CONV_FWD', '3') != '2'
+if V3:
+    # conv_fwd3_kernel: stamps of the last 8 slots of workgroup 77, wave 0 (group A: even slots MFMA, odd slots staging)
+    names = {}
+    for sl in range(8):
+        kind = 'mfma(+epilogue)' if sl % 2 == 0 else 'commit+issue'
+        names[1 + 3 * sl] = 'slot%d start' % sl
+        names[2 + 3 * sl] = 'slot%d %s done' % (sl, kind)
+        names[3 + 3 * sl] = 'slot%d barrier passed' % sl
+        if sl % 2:
+            names[40 + 2 * sl] = 'slot%d   loads landed' % sl
+            names[41 + 2 * sl] = 'slot%d   committed to LDS' % sl
+    print('workgroup 77: %d stages, kernel start -> end %d ticks (%.0f per stage)' % (t[62], t[61] - t[60], (t[61] - t[60]) / max(t[62], 1)))
+    order = sorted(names, key=lambda i: t[i])
+    prev = t[order[0]]
+    for i in order:
+        print('%-32s +%7d' % (names[i], t[i] - prev))
+        prev = t[i]
+    sys.exit(0)
 for c in range(4):
-    if V3:
-        names[1 + 5 * c] = 'chunk%d next-stage loads issued' % c
-        names[2 + 5 * c] = 'chunk%d mfma done' % c
-        names[3 + 5 * c] = 'chunk%d next stage committed' % c
-        names[4 + 5 * c] = 'chunk%d barrier passed' % c
-    else:
-        names[1 + 5 * c] = 'chunk%d commit done' % c
-        names[2 + 5 * c] = 'chunk%d barrier1 passed' % c
-        names[3 + 5 * c] = 'chunk%d prefetch issued' % c
-        names[4 + 5 * c] = 'chunk%d mfma done' % c
-        names[5 + 5 * c] = 'chunk%d barrier2 passed' % c
+    names[1 + 5 * c] = 'chunk%d commit done' % c
+    names[2 + 5 * c] = 'chunk%d barrier1 passed' % c
+    names[3 + 5 * c] = 'chunk%d prefetch issued' % c
+    names[4 + 5 * c] = 'chunk%d mfma done' % c
+    names[5 + 5 * c] = 'chunk%d barrier2 passed' % c
 names[30] = 'epilogue issued'
-if not V3:
-    names[31] = 'next tile prefetch issued'
+names[31] = 'next tile prefetch issued'
 prev = t[0]
 for i in sorted(names):
     print('%-28s +%7d  (t=%d)' % (names[i], t[i] - prev, t[i] - t[0]))
