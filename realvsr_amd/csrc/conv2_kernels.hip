@@ -433,9 +433,16 @@ __global__ __launch_bounds__(512, 2) void conv_fwd3_kernel(const ConvFwdParams p
                 const int r = pos / IW, s = pos - r * IW;
                 const int gy = t.y0 - PAD + r, gx = t.x0 - PAD + s;
                 it_oc[i] = oc;
-                it_pos_ok[i] = live && gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv;
+                bool ok = live && gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv;
                 const int gyc = gy < 0 ? 0 : (gy >= va.Hv ? va.Hv - 1 : gy), gxc = gx < 0 ? 0 : (gx >= va.Wv ? va.Wv - 1 : gx);
-                it_sp[i] = va.mode == 0 ? gyc * va.Ws + gxc : (2 * gyc) * va.Ws + 2 * gxc;
+                if (va.mode == 1) {  // zero-insert view: only even (y, x) carry data
+                    const int ys = gyc >> 1, xs = gxc >> 1;
+                    ok = ok && !((gyc | gxc) & 1) && ys < va.Hs && xs < va.Ws;
+                    it_sp[i] = (ys < va.Hs ? ys : 0) * va.Ws + (xs < va.Ws ? xs : 0);
+                } else {
+                    it_sp[i] = va.mode == 0 ? gyc * va.Ws + gxc : (2 * gyc) * va.Ws + 2 * gxc;
+                }
+                it_pos_ok[i] = ok;
                 it_dst[i] = live ? it : -100;
             }
         }
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd3_kernel(const ConvFwdParams p
         for (int i = 0; i < NIT; ++i) {
             const int cb = c0 + it_oc[i] * 8;
             const bool inb = it_pos_ok[i] && cb < Ctot;
-            if (VEC || va.mode == 0) {  // (uniform branch)
+            if (VEC || va.mode != 2) {  // (uniform branch)
                 const bool second = inb && cb >= C1;  // octets never straddle the two inputs (C1 % 8 == 0)
                 const float* bp = second ? vb.p : va.p;
                 const float* ap = va.act;
@@ -1046,5 +1053,102 @@ int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_
     hipLaunchKernelGGL(k, dim3(p.P, gy, gz), dim3(WG2_THREADS), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+// ==========================================================================================
+// Weight gradient of a 1x1 convolution on the bf16 matrix cores: a plain GEMM
+//   gW[o][c] = sum_px G[o][px] * X[c][px],   K = pixels.
+// Both MFMA operands want 8 consecutive K (= pixels) per lane, which is the NCHW memory order, so the fragments
+// are loaded straight from global memory with 16-byte loads (no LDS): lane l of a wave reads pixels
+// 8*(l>>5) .. +7 of row (l & 31).  One workgroup = 4 waves = a 64(o) x 64(c) block of gW, one 32x32 tile per wave,
+// over a slice of the pixels (K split, partial sums reduced by rvsr_reduce_partials_kernel).  The kernel is
+// L1-bandwidth-bound (every wave streams its G and X rows), ~10x faster than the exact-f32 LDS-staged kernel it
+// replaces for the 320->64 / 64->64 fusion convs of TSA.
+template <bool ACT>
+__global__ __launch_bounds__(256, 4) void conv_wgrad1x1_kernel(const ConvWgradParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int m = wave & 1, n = wave >> 1;
+    const int C1 = p.x.a.C, Ctot = C1 + p.x.b.C;
+    const int HW = p.Hout * p.Wout;
+    const int o = blockIdx.y * 64 + m * 32 + lo;   // this lane's G row
+    const int c = blockIdx.z * 64 + n * 32 + lo;   // this lane's X row
+    const bool o_ok = o < p.Co, c_ok = c < Ctot;
+    const bool second = c_ok && c >= C1;
+    const float* xrow0 = second ? p.x.b.p : p.x.a.p;
+    const int Cb = second ? p.x.b.C : C1, cl = c_ok ? (second ? c - C1 : c) : 0;
+    const int oc = o_ok ? o : 0;
+    const int U = (HW + 31) / 32;  // 32-pixel units per image
+    const long units = (long)p.B * U;
+    const long per = (units + p.P - 1) / p.P;
+    long u0 = (long)blockIdx.x * per, u1 = u0 + per;
+    if (u1 > units) u1 = units;
+    f32x16 acc = zero16();
+    float bsum = 0.f;
+    for (long u = u0; u < u1; ++u) {
+        const int b = (int)(u / U), px0 = (int)(u - (long)b * U) * 32;
+        const float* gp = p.g.p + ((size_t)b * p.Co + oc) * HW;
+        const float* ap = ACT ? p.g.act + ((size_t)b * p.Co + oc) * HW : nullptr;
+        const float* xp = xrow0 + ((size_t)b * Cb + cl) * HW;
+        float4 g4[4], a4[ACT ? 4 : 1], x4[4];
+        bool pv[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int px = px0 + 16 * s2 + 8 * hi;
+            pv[s2] = px < HW;  // HW % 8 == 0: the 8-pixel group is entirely inside or outside
+            const int pc = pv[s2] ? px : 0;
+            g4[2 * s2] = *reinterpret_cast<const float4*>(gp + pc);
+            g4[2 * s2 + 1] = *reinterpret_cast<const float4*>(gp + pc + 4);
+            x4[2 * s2] = *reinterpret_cast<const float4*>(xp + pc);
+            x4[2 * s2 + 1] = *reinterpret_cast<const float4*>(xp + pc + 4);
+            if (ACT) {
+                a4[2 * s2] = *reinterpret_cast<const float4*>(ap + pc);
+                a4[2 * s2 + 1] = *reinterpret_cast<const float4*>(ap + pc + 4);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float gv[8] = {g4[2 * s2].x, g4[2 * s2].y, g4[2 * s2].z, g4[2 * s2].w,
+                           g4[2 * s2 + 1].x, g4[2 * s2 + 1].y, g4[2 * s2 + 1].z, g4[2 * s2 + 1].w};
+            float xv[8] = {x4[2 * s2].x, x4[2 * s2].y, x4[2 * s2].z, x4[2 * s2].w,
+                           x4[2 * s2 + 1].x, x4[2 * s2 + 1].y, x4[2 * s2 + 1].z, x4[2 * s2 + 1].w};
+            if (ACT) {
+                const float av[8] = {a4[2 * s2].x, a4[2 * s2].y, a4[2 * s2].z, a4[2 * s2].w,
+                                     a4[2 * s2 + 1].x, a4[2 * s2 + 1].y, a4[2 * s2 + 1].z, a4[2 * s2 + 1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[j] *= av[j] > 0.f ? 1.f : p.g.slope;
+            }
+            const bool gok = pv[s2] && o_ok, xok = pv[s2] && c_ok;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gv[j] = gok ? gv[j] : 0.f;
+                xv[j] = xok ? xv[j] : 0.f;
+                bsum += gv[j];
+            }
+            bf16x8 gh, gl, xh, xl;
+            split8(gv, gh, gl);
+            split8(xv, xh, xl);
+            acc = mfma_bf16(gh, xh, acc);
+            acc = mfma_bf16(gh, xl, acc);
+            acc = mfma_bf16(gl, xh, acc);
+        }
+    }
+    float* part = p.part + (size_t)blockIdx.x * p.Co * Ctot;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int orow = blockIdx.y * 64 + m * 32 + drow(r, hi);
+        if (orow < p.Co && c_ok) part[(size_t)orow * Ctot + c] = acc[r];
+    }
+    if (p.bpart != nullptr && blockIdx.z == 0 && n == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (hi == 0 && o_ok) p.bpart[(size_t)blockIdx.x * p.Co + o] = bsum;
+    }
+}
+
+int rvsr_launch_conv_wgrad1x1(const ConvWgradParams& p, int gy, int gz, hipStream_t st) {
+    auto k = p.g.act != nullptr ? conv_wgrad1x1_kernel<true> : conv_wgrad1x1_kernel<false>;
+    hipLaunchKernelGGL(k, dim3(p.P, gy, gz), dim3(256), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad1x1 launch: %s", hipGetErrorString(e));
     return RVSR_OK;
 }

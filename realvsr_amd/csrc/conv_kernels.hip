@@ -294,7 +294,7 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
     p.ntx = (Wout + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     p.wpack = nullptr;
-    if (rvsr_g_gemm_mode == 0 && (in_mode == 0 || in_mode == 2) && (x2 == nullptr || C1 % 8 == 0))
+    if (rvsr_g_gemm_mode == 0 && (in_mode != 1 || ksize == 3) && (x2 == nullptr || C1 % 8 == 0))
         return rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
     const int mt = p.Co <= 32 ? 1 : (p.Co <= 64 ? 2 : 4);
 #define DISPATCH(KS, S, CC12, CC4)                                \
@@ -316,8 +316,9 @@ extern "C" size_t rvsr_conv2d_forward_workspace_bytes(int C1, int C2, int Co, in
     return rvsr_conv_fwd2_workspace_bytes(ksize, Co, C1 + C2);
 }
 
-static int wgrad_P(int ntiles, int gy, int gz) {
-    int P = 256 / (gy * gz);
+static int wgrad_P(int ntiles, int gy, int gz, int ksize) {
+    // 1x1: the GEMM kernel runs 4 small workgroups per CU and hides its load latency with occupancy
+    int P = (ksize == 1 ? 1024 : 256) / (gy * gz);
     if (P < 1) P = 1;
     if (P > ntiles) P = ntiles;
     return P;
@@ -333,7 +334,7 @@ extern "C" size_t rvsr_conv2d_wgrad_workspace_bytes(int C1, int C2, int Co, int 
     int ccw, gy, gz;
     wgrad_geom(ksize, stride, Co, C1 + C2, ccw, gy, gz);
     const int ntiles = B * ((Hout + 3) / 4) * ((Wout + 31) / 32);
-    const size_t P = wgrad_P(ntiles, gy, gz);
+    const size_t P = wgrad_P(ntiles, gy, gz, ksize);
     return sizeof(float) * P * ((size_t)Co * (C1 + C2) * ksize * ksize + Co);
 }
 
@@ -380,7 +381,7 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     p.Wout = Wout;
     p.ntx = (Wout + 31) / 32;
     p.nty = (Hout + 3) / 4;
-    p.P = wgrad_P(B * p.nty * p.ntx, gy, gz);
+    p.P = wgrad_P(B * p.nty * p.ntx, gy, gz, ksize);
     const size_t nw = (size_t)Co * Ctot * ksize * ksize;
     p.part = (float*)workspace;
     p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;
@@ -389,6 +390,8 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     const bool aligned16 = ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)gout) | ((uintptr_t)gact)) & 15) == 0;
     if (rvsr_g_gemm_mode == 0 && ksize == 3 && stride == 1 && (Wout % 4) == 0 && aligned16)
         rc = rvsr_launch_conv_wgrad2(p, gy, gz, st);
+    else if (rvsr_g_gemm_mode == 0 && ksize == 1 && g_mode == 0 && ((Hout * Wout) % 8) == 0 && aligned16)
+        rc = rvsr_launch_conv_wgrad1x1(p, gy, gz, st);
     else if (ksize == 3 && stride == 1)
         rc = launch_wgrad<3, 1, 64>(p, gy, gz, st);
     else if (ksize == 3)

@@ -27,6 +27,8 @@ CASES = [
     (320, 0, 64, 1, 1, 'lrelu', False, False, 1, 16, 40),
     (48, 0, 16, 1, 1, 'none', False, False, 2, 12, 20),
     (32, 32, 16, 1, 1, 'lrelu', False, False, 1, 9, 33),
+    (64, 64, 80, 1, 1, 'lrelu', False, False, 2, 10, 36),   # concat 1x1 on the GEMM weight-gradient path (HW % 8 == 0)
+    (64, 0, 64, 3, 2, 'relu', False, False, 1, 23, 37),      # odd sizes through the zero-insert data gradient
     (128, 0, 128, 3, 1, 'relu', False, False, 1, 12, 36),
     (64, 0, 64, 3, 1, 'lrelu', True, False, 1, 16, 24),   # act + residual (sAtt_3 pattern)
 ]
