@@ -582,11 +582,25 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
         const int ty = trem / d.ntx, tx = trem - ty * d.ntx;
         const int y0 = ty * 4, x0 = tx * 32;
         const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;
+        // thread t stages pixel (t & 127) for output channels 4*(t >> 7) + 16*i + 0..3, four at a time (one batch of
+        // loads in flight: the 96 accumulator registers leave no room for more)
+        if (p.g.mode == 0) {  // (uniform)
+            const int px = tid & 127, og = tid >> 7;
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int ol = 16 * i + 4 * og;
+                float v4[4];
+                tview_get_plain<4>(p.g, b, mb * 64 + ol, y0 + (px >> 5), x0 + (px & 31), v4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gT[px * GP + ol + j] = v4[j];
+            }
+        } else {
 #pragma unroll 2
-        for (int e = tid; e < 64 * DCN_NPX; e += NT) {
-            const int ol = e >> 7, px = e & 127;
-            const int o = mb * 64 + ol;
-            gT[px * GP + ol] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
+            for (int e = tid; e < 64 * DCN_NPX; e += NT) {
+                const int ol = e >> 7, px = e & 127;
+                const int o = mb * 64 + ol;
+                gT[px * GP + ol] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
+            }
         }
         stage_x_tile<NT, 2, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
         __syncthreads();
@@ -810,18 +824,22 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     float4* myp = priv + (wave * 2 + hi) * PPOS;
     volatile int* myc = claim + (wave * 2 + hi) * PPOS;
 
+    DSTAMP(100);
     bf16x8 gh[NK], gl[NK];
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
         float v[8];
+        if (p.g.mode == 0) {  // (uniform)
+            tview_get_plain<8>(p.g, b, 8 * (2 * ks + hi), oy, ox, v);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int o = 8 * (2 * ks + hi) + j;
-            v[j] = (px_ok && o < d.Co) ? tview_get(p.g, b, o, oy, ox) : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = tview_get(p.g, b, 8 * (2 * ks + hi) + j, oy, ox);
         }
         split8(v, gh[ks], gl[ks]);
     }
+    DSTAMP(101);
     for (int e = tid; e < D3_TH * 2 * PPOS; e += NT) priv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    DSTAMP(102);
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * 8;
@@ -845,8 +863,11 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
 #pragma unroll 3
             for (int e = tid; e < 3 * WBLK; e += NT) wsb[e] = src[e];
         }
+        if (chunk < 3) DSTAMP(103 + 5 * chunk);
         stage_x_tile<NT, 2, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
+        if (chunk < 3) DSTAMP(104 + 5 * chunk);
         __syncthreads();
+        if (chunk < 3) DSTAMP(105 + 5 * chunk);
 
         const int cq = c0 + 4 * hi;  // this lane's first channel
 #pragma unroll
@@ -865,6 +886,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
             for (int tsel = 0; tsel < 4; ++tsel) {
                 const int tap = 4 * mt + tsel;
                 if (tap >= 9) continue;  // uniform
+                if (chunk == 1 && tap < 4) DSTAMP(140 + 4 * tap);
                 float gy_s = 0.f, gx_s = 0.f, gm_s = 0.f, m = 0.f;
                 bool inside = false, in_win = false;
                 float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
@@ -922,6 +944,10 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                         }
                     }
                 }
+#ifdef RVSR_TIMELINE_DCN
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (chunk == 1 && tap < 4) DSTAMP(141 + 4 * tap);
+#endif
                 // ---- scatter (all lanes take part in the claim rounds; `pend` carries the per-lane predicate)
                 {
                     const int pr0 = r0 - wave, pr1 = r1 - wave;
@@ -931,7 +957,39 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                                             make_float4(w01 * t[0], w01 * t[1], w01 * t[2], w01 * t[3]),
                                             make_float4(w10 * t[0], w10 * t[1], w10 * t[2], w10 * t[3]),
                                             make_float4(w11 * t[0], w11 * t[1], w11 * t[2], w11 * t[3])};
-                    claim_add4(myc, myp, cidx, cval, go && w00 != 0.f, go && w01 != 0.f, go && w10 != 0.f, go && w11 != 0.f, lane);
+                    const bool p0 = go && w00 != 0.f, p1 = go && w01 != 0.f, p2 = go && w10 != 0.f, p3 = go && w11 != 0.f;
+                    // Fast path without claim traffic.  Pixels of equal parity are two columns apart, so for offsets that
+                    // differ by less than a pixel between neighbours (floor flips of at most 1) their left sample
+                    // column s0 is strictly increasing; the wave checks exactly that (key[l] > key[l-2]).  Then, within
+                    // one parity class, no two lanes share a column: the "left" corners (00, 10) hit pairwise
+                    // different cells and so do the "right" ones (01, 11; s1 = s0 + 1 whenever the corner is valid,
+                    // invalid corners have weight 0 and are skipped).  The four (parity, side) groups are applied one
+                    // after the other as plain read-modify-writes (LDS operations of a wave execute in order).
+                    // Anything else takes the exact claim rounds.  Lanes that do not scatter stand in with the
+                    // zero-offset column so they do not break the test.
+                    const int key = go ? s0 : lo + D3_R + tap % 3;
+                    const int left2 = __shfl_up(key, 2);
+                    if (__all(lo < 2 || key > left2)) {
+#pragma unroll
+                        for (int par = 0; par < 2; ++par) {  // even pixels, then odd pixels
+                            const bool mine = (lo & 1) == par;
+                            float4 v0 = myp[cidx[0]], v2 = myp[cidx[2]];
+                            v0.x += cval[0].x; v0.y += cval[0].y; v0.z += cval[0].z; v0.w += cval[0].w;
+                            v2.x += cval[2].x; v2.y += cval[2].y; v2.z += cval[2].z; v2.w += cval[2].w;
+                            if (mine && p0) myp[cidx[0]] = v0;
+                            if (mine && p2) myp[cidx[2]] = v2;
+                            asm volatile("" ::: "memory");
+                            float4 v1 = myp[cidx[1]], v3 = myp[cidx[3]];
+                            v1.x += cval[1].x; v1.y += cval[1].y; v1.z += cval[1].z; v1.w += cval[1].w;
+                            v3.x += cval[3].x; v3.y += cval[3].y; v3.z += cval[3].z; v3.w += cval[3].w;
+                            if (mine && p1) myp[cidx[1]] = v1;
+                            if (mine && p3) myp[cidx[3]] = v3;
+                            asm volatile("" ::: "memory");
+                        }
+                    } else {
+                        claim_add4(myc, myp, cidx, cval, p0, p1, p2, p3, lane);
+                    }
+                    if (chunk == 1 && tap < 4) DSTAMP(142 + 4 * tap);
                     if (inside && !in_win) {  // large offset: straight to global memory
                         float* gp = p.gx + ((size_t)b * d.C + cq) * HW;
                         const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
@@ -946,6 +1004,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                         }
                     }
                 }
+                if (chunk == 1 && tap < 4) DSTAMP(143 + 4 * tap);
                 gy_s += __shfl_xor(gy_s, 32);
                 gx_s += __shfl_xor(gx_s, 32);
                 gm_s += __shfl_xor(gm_s, 32);
@@ -965,6 +1024,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                 }
             }
         }
+        if (chunk < 3) DSTAMP(106 + 5 * chunk);
         __syncthreads();
         // ---- merge the private windows: owner thread per (quad, shared row, col)
         for (int it = tid; it < 2 * NPOS; it += NT) {
@@ -989,8 +1049,10 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                 if (cb + 3 < d.C && sum.w != 0.f) atomicAdd(q + 3 * HW, sum.w);
             }
         }
+        if (chunk < 3) DSTAMP(107 + 5 * chunk);
         __syncthreads();
     }
+    DSTAMP(130);
 }
 
 static int nk_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : (Co <= 64 ? 4 : 8)); }

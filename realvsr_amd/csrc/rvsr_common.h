@@ -92,6 +92,41 @@ __device__ __forceinline__ float tview_get(const TView& v, int b, int c, int y, 
     return ok ? val : 0.f;
 }
 
+// N consecutive channels c0 .. c0+N-1 of a PLAIN (mode 0) view at one pixel: all loads of the batch are issued before
+// any value is used.  tview_get() in a loop costs one L2/HBM round trip per element as soon as the call sits under a
+// condition or the view has an `act` tensor (the uniform `act != nullptr` branch splits the loop body into basic
+// blocks that hipcc does not schedule loads across): measured 52 K cycles for the 32 gradient values of a lane.
+template <int N>
+__device__ __forceinline__ void tview_get_plain(const TView& v, int b, int c0, int y, int x, float (&out)[N]) {
+    const bool pok = y >= 0 && x >= 0 && y < v.Hv && x < v.Wv;
+    const size_t hw = (size_t)v.Hs * v.Ws;
+    const size_t sp = pok ? (size_t)y * v.Ws + x : 0;
+    size_t idx[N];
+    bool ok[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int c = c0 + j;
+        ok[j] = pok && c >= 0 && c < v.C;
+        idx[j] = ((size_t)b * v.C + (ok[j] ? c : 0)) * hw + sp;
+    }
+    if (v.act != nullptr) {  // (uniform, around the whole batch)
+        float raw[N], a[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            raw[j] = v.p[idx[j]];
+            a[j] = v.act[idx[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) out[j] = ok[j] ? raw[j] * (a[j] > 0.f ? 1.f : v.slope) : 0.f;
+    } else {
+        float raw[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) raw[j] = v.p[idx[j]];
+#pragma unroll
+        for (int j = 0; j < N; ++j) out[j] = ok[j] ? raw[j] : 0.f;
+    }
+}
+
 // two views concatenated along channels (torch.cat([a, b], 1) without materialising it)
 struct TCat {
     TView a, b;  // b.p == nullptr -> single input

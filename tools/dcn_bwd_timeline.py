@@ -23,7 +23,12 @@ for c in range(3):
     names[106 + 5 * c] = 'chunk%d 3 M tiles (mfma+consume+scatter)' % c
     names[107 + 5 * c] = 'chunk%d barrier + merge' % c
 names[130] = 'end (8 chunks)'
+for tp in range(4):
+    names[140 + 4 * tp] = '  chunk1 tap%d start' % tp
+    names[141 + 4 * tp] = '  chunk1 tap%d sampled + consumer math done' % tp
+    names[142 + 4 * tp] = '  chunk1 tap%d claim/scatter done' % tp
+    names[143 + 4 * tp] = '  chunk1 tap%d far-offset path passed' % tp
 prev = t[100]
-for i in sorted(names):
+for i in sorted(names, key=lambda i: t[i]):
     print('%-44s +%7d  (t=%d)' % (names[i], t[i] - prev, t[i] - t[100]))
     prev = t[i]
