@@ -27,7 +27,7 @@ def make_layer(basic_block, num_basic_block, **kwarg):
 
 class ResidualBlock_noBN(nn.Module):
     """x + conv2(relu(conv1(x))): two fused kernels (ReLU in conv1's epilogue, the identity add
-    in conv2's)."""
+    in conv2's); in backward the identity gradient is added by conv1's data-gradient kernel."""
 
     def __init__(self, nf=64):
         super(ResidualBlock_noBN, self).__init__()
@@ -36,5 +36,4 @@ class ResidualBlock_noBN(nn.Module):
         initialize_weights([self.conv1, self.conv2], 0.1)
 
     def forward(self, x):
-        out = RF.conv2d(x, self.conv1, act=RF.ACT_RELU)
-        return RF.conv2d(out, self.conv2, residual=x)
+        return RF.res_block(x, self.conv1, self.conv2)

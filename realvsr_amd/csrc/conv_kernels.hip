@@ -147,23 +147,70 @@ __global__ __launch_bounds__(RVSR_WG) void conv_wgrad_kernel(const ConvWgradPara
         const int trem = tile - b * (p.nty * p.ntx);
         const int ty = trem / p.ntx, tx = trem - ty * p.ntx;
         const int y0 = ty * TH, x0 = tx * TW;
+        // plain views (the common case) are staged four elements per batch of loads, see tview_get_batch
+        if (p.g.mode == 0) {  // (uniform)
+            for (int e0 = tid; e0 < 64 * NPX; e0 += 4 * RVSR_WG) {
+                int cc[4], yy[4], xx[4];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j * RVSR_WG;
+                    const int ol = e / NPX, px = e - ol * NPX;
+                    cc[j] = e < 64 * NPX ? mb * 64 + ol : -1;
+                    yy[j] = y0 + (px >> 5);
+                    xx[j] = x0 + (px & 31);
+                }
+                tview_get_batch<4>(p.g, b, cc, yy, xx, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j * RVSR_WG;
+                    const int ol = e / NPX, px = e - ol * NPX;
+                    if (e < 64 * NPX) gT[px * GP + ol] = v[j];
+                }
+            }
+        } else {
 #pragma unroll 2
-        for (int e = tid; e < 64 * NPX; e += RVSR_WG) {
-            const int ol = e / NPX, px = e - ol * NPX;
-            const int o = mb * 64 + ol;
-            float v = 0.f;
-            if (o < p.Co) v = tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31));
-            gT[px * GP + ol] = v;
+            for (int e = tid; e < 64 * NPX; e += RVSR_WG) {
+                const int ol = e / NPX, px = e - ol * NPX;
+                const int o = mb * 64 + ol;
+                float v = 0.f;
+                if (o < p.Co) v = tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31));
+                gT[px * GP + ol] = v;
+            }
         }
+        if (p.x.b.p == nullptr && p.x.a.mode == 0) {  // (uniform)
+            for (int e0 = tid; e0 < CCW * IH * IW; e0 += 4 * RVSR_WG) {
+                int cc[4], yy[4], xx[4];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j * RVSR_WG;
+                    const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+                    const int r = rem / IW, s = rem - r * IW;
+                    cc[j] = e < CCW * IH * IW ? c0 + ci : -1;
+                    yy[j] = y0 * STRIDE - PAD + r;
+                    xx[j] = x0 * STRIDE - PAD + s;
+                }
+                tview_get_batch<4>(p.x.a, b, cc, yy, xx, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + j * RVSR_WG;
+                    const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+                    const int r = rem / IW, s = rem - r * IW;
+                    if (e < CCW * IH * IW) xs[ci * CS + r * IW + s] = v[j];
+                }
+            }
+        } else {
 #pragma unroll 2
-        for (int e = tid; e < CCW * IH * IW; e += RVSR_WG) {
-            const int cc = e / (IH * IW);
-            const int rem = e - cc * (IH * IW);
-            const int r = rem / IW, s = rem - r * IW;
-            const int c = c0 + cc;
-            float v = 0.f;
-            if (c < Ctot) v = tcat_get(p.x, b, c, y0 * STRIDE - PAD + r, x0 * STRIDE - PAD + s);
-            xs[cc * CS + r * IW + s] = v;
+            for (int e = tid; e < CCW * IH * IW; e += RVSR_WG) {
+                const int cc = e / (IH * IW);
+                const int rem = e - cc * (IH * IW);
+                const int r = rem / IW, s = rem - r * IW;
+                const int c = c0 + cc;
+                float v = 0.f;
+                if (c < Ctot) v = tcat_get(p.x, b, c, y0 * STRIDE - PAD + r, x0 * STRIDE - PAD + s);
+                xs[cc * CS + r * IW + s] = v;
+            }
         }
         __syncthreads();
         if (p.bpart != nullptr && blockIdx.z == 0 && tid < 64) {

@@ -57,8 +57,11 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gout, float* __res
         const int iy = (int)((i / W) % H);
         const size_t pl = i / ((size_t)W * H);
         const float* g = gout + pl * Ho * Wo;
-        const int oy_lo = max(0, S * iy - 2 * S), oy_hi = min(Ho - 1, S * iy + 2 * S);
-        const int ox_lo = max(0, S * ix - 2 * S), ox_hi = min(Wo - 1, S * ix + 2 * S);
+        // outputs that can read input row iy: for S = 2 exactly rows 2iy-1 .. 2iy+2 (source coordinate oy/2 - 1/4);
+        // other factors use a conservative window, rows outside get weight 0 below
+        const int e_lo = S == 2 ? 1 : 2 * S, e_hi = S == 2 ? 2 : 2 * S;
+        const int oy_lo = max(0, S * iy - e_lo), oy_hi = min(Ho - 1, S * iy + e_hi);
+        const int ox_lo = max(0, S * ix - e_lo), ox_hi = min(Wo - 1, S * ix + e_hi);
         float acc = 0.f;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             const Lerp ly = up_src(oy, S, H);

@@ -92,22 +92,20 @@ __device__ __forceinline__ float tview_get(const TView& v, int b, int c, int y, 
     return ok ? val : 0.f;
 }
 
-// N consecutive channels c0 .. c0+N-1 of a PLAIN (mode 0) view at one pixel: all loads of the batch are issued before
-// any value is used.  tview_get() in a loop costs one L2/HBM round trip per element as soon as the call sits under a
-// condition or the view has an `act` tensor (the uniform `act != nullptr` branch splits the loop body into basic
-// blocks that hipcc does not schedule loads across): measured 52 K cycles for the 32 gradient values of a lane.
+// N elements (c[j], y[j], x[j]) of a PLAIN (mode 0) view: all loads of the batch are issued before any value is used.
+// tview_get() in a loop costs one L2/HBM round trip per element as soon as the call sits under a condition or the
+// view has an `act` tensor (the uniform `act != nullptr` branch splits the loop body into basic blocks that hipcc
+// does not schedule loads across): measured 52 K cycles for the 32 gradient values of a lane.
 template <int N>
-__device__ __forceinline__ void tview_get_plain(const TView& v, int b, int c0, int y, int x, float (&out)[N]) {
-    const bool pok = y >= 0 && x >= 0 && y < v.Hv && x < v.Wv;
+__device__ __forceinline__ void tview_get_batch(const TView& v, int b, const int (&c)[N], const int (&y)[N], const int (&x)[N],
+                                                float (&out)[N]) {
     const size_t hw = (size_t)v.Hs * v.Ws;
-    const size_t sp = pok ? (size_t)y * v.Ws + x : 0;
     size_t idx[N];
     bool ok[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const int c = c0 + j;
-        ok[j] = pok && c >= 0 && c < v.C;
-        idx[j] = ((size_t)b * v.C + (ok[j] ? c : 0)) * hw + sp;
+        ok[j] = y[j] >= 0 && x[j] >= 0 && y[j] < v.Hv && x[j] < v.Wv && c[j] >= 0 && c[j] < v.C;
+        idx[j] = ok[j] ? ((size_t)b * v.C + c[j]) * hw + (size_t)y[j] * v.Ws + x[j] : 0;
     }
     if (v.act != nullptr) {  // (uniform, around the whole batch)
         float raw[N], a[N];
@@ -125,6 +123,18 @@ __device__ __forceinline__ void tview_get_plain(const TView& v, int b, int c0, i
 #pragma unroll
         for (int j = 0; j < N; ++j) out[j] = ok[j] ? raw[j] : 0.f;
     }
+}
+// N consecutive channels c0 .. c0+N-1 at one pixel
+template <int N>
+__device__ __forceinline__ void tview_get_plain(const TView& v, int b, int c0, int y, int x, float (&out)[N]) {
+    int c[N], yy[N], xx[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        c[j] = c0 + j;
+        yy[j] = y;
+        xx[j] = x;
+    }
+    tview_get_batch<N>(v, b, c, yy, xx, out);
 }
 
 // two views concatenated along channels (torch.cat([a, b], 1) without materialising it)

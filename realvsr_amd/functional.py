@@ -113,6 +113,78 @@ class _Conv2dFused(Function):
         return gx1, gx2, gw, gb, gres, None, None, None, None
 
 
+class _ResBlockFused(Function):
+    """x + conv2(relu(conv1(x))) as ONE autograd node (arch_util.ResidualBlock_noBN, reference
+    codes/models/archs/arch_util.py:37-52).  Forward is the same two fused kernels as two conv2d()
+    calls; the point is the backward: grad_x = grad_out + dgrad1(...) is produced by conv1's
+    data-gradient kernel with grad_out as its fused residual, instead of a separate full-tensor
+    add by autograd (3 passes over a B x 64 x H x W tensor per block)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _need_cuda(x, w1, b1, w2, b2)
+        x, w1, b1, w2, b2 = _c(x), _c(w1), _c(b1), _c(w2), _c(b2)
+        B, C, H, W = x.shape
+        if w1.shape != (C, C, 3, 3) or w2.shape != (C, C, 3, 3):
+            raise RuntimeError('res_block: expected two %dx%dx3x3 convs' % (C, C))
+        L = _lib.lib()
+        h, out = torch.empty_like(x), torch.empty_like(x)
+        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), x.device)
+        _lib.check(L.rvsr_conv2d_forward(_p(x), C, None, 0, None, 0.0, 0, H, W, _p(w1), _p(b1), None, _p(h), C, None,
+                                         0, B, 3, 1, 0, ACT_RELU, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                   'res_block conv1')
+        _lib.check(L.rvsr_conv2d_forward(_p(h), C, None, 0, None, 0.0, 0, H, W, _p(w2), _p(b2), _p(x), _p(out), C,
+                                         None, 0, B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                   'res_block conv2')
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, h, w1, w2 = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, C, H, W = x.shape
+        L = _lib.lib()
+        need_x, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        nb = L.rvsr_conv2d_wgrad_workspace_bytes(C, 0, C, B, 3, 1, H, W)
+        if need_w2 or need_b2:
+            gw2 = torch.empty_like(w2)
+            gb2 = w2.new_empty(C) if ctx.has_bias[1] else None
+            ws = _workspace(nb, x.device)
+            _lib.check(L.rvsr_conv2d_backward_weight(_p(h), C, None, 0, H, W, _p(gout), None, 0.0, 0, H, W, _p(gw2),
+                                                     _p(gb2), C, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()),
+                       'res_block wgrad2')
+        if need_x or need_w1 or need_b1:
+            # gradient w.r.t. relu(conv1(x)); relu' is applied from h when it is consumed below
+            gh = torch.empty_like(x)
+            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), x.device)
+            _lib.check(L.rvsr_conv2d_forward(_p(gout), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, None, _p(gh), C,
+                                             None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(),
+                                             _stream()), 'res_block dgrad2')
+            if need_w1 or need_b1:
+                gw1 = torch.empty_like(w1)
+                gb1 = w1.new_empty(C) if ctx.has_bias[0] else None
+                ws = _workspace(nb, x.device)
+                _lib.check(L.rvsr_conv2d_backward_weight(_p(x), C, None, 0, H, W, _p(gh), _p(h), 0.0, 0, H, W,
+                                                         _p(gw1), _p(gb1), C, B, 3, 1, H, W, 0, _p(ws), ws.numel(),
+                                                         _stream()), 'res_block wgrad1')
+            if need_x:
+                gx = torch.empty_like(x)
+                ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), x.device)
+                _lib.check(L.rvsr_conv2d_forward(_p(gh), C, None, 0, _p(h), 0.0, 0, H, W, _p(w1), None, _p(gout),
+                                                 _p(gx), C, None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws),
+                                                 ws.numel(), _stream()), 'res_block dgrad1')
+        return gx, gw1, gb1, gw2, gb2
+
+
+def res_block(x, conv1, conv2):
+    """x + conv2(relu(conv1(x))) with the identity add fused in both directions."""
+    return _ResBlockFused.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
+
+
 def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False):
     """Fused conv block driven by an ``nn.Conv2d`` parameter holder (weight, bias, stride).
 
