@@ -202,6 +202,16 @@ int rvsr_gwloss_forward(const float* x1, const float* x2, size_t planes, int H, 
 int rvsr_gwloss_backward(const float* fa, const float* fbx, const float* fby, const float* gscalar, float scale, float* gx,
                          size_t planes, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 5. Test-time output conversion
+ * --------------------------------------------------------------------------------------------- */
+
+/* ycc: planar f32 [3][H][W] network output (Y, Cb, Cr in [0, 1] nominal) -> bgr: uint8 [H][W][3].
+ * Replaces the host-side numpy chain of codes/test_RealVSR_wi_GT.py:122-123
+ * (utils/util.py:151-181 tensor2img(float32, reverse_channel=False) -> data/util.py:397-416 ycbcr2bgr ->
+ * clip, *255, round, uint8), same arithmetic order and precisions: bit-exact. */
+int rvsr_ycbcr_to_bgr_u8(const float* ycc, unsigned char* bgr, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ SIGNATURES = {
     'rvsr_charbonnier_backward': (c_int, [c_fp, c_fp, c_fp, c_float, c_float, c_fp, c_size, c_fp]),
     'rvsr_gwloss_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'rvsr_gwloss_backward': (c_int, [c_fp, c_fp, c_fp, c_fp, c_float, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_ycbcr_to_bgr_u8': (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
 }
 
 

@@ -161,24 +161,24 @@ class _EDVRBase(nn.Module):
         self.HRconv = nn.Conv2d(64, 64, 3, 1, 1, bias=True)
         self.conv_last = nn.Conv2d(64, nc, 3, 1, 1, bias=True)
 
-    def forward(self, x):
+    def extract_features(self, frames):
+        """Per-frame part of the network (EDVR_arch.py:275-289): conv_first, the front residual blocks and the
+        L2/L3 pyramid convs on a [M, C, H, W] stack of frames.  It does not depend on which window a frame is in,
+        which is what the sliding-window driver (realvsr_amd/infer.py) exploits."""
         conv = RF.conv2d
-        B, N, C, H, W = x.size()  # N video frames
-        if H % 4 or W % 4:
-            raise RuntimeError('EDVR needs H and W divisible by 4 (got %dx%d)' % (H, W))
-        x = x.contiguous()
-        x_center = x[:, self.center, :, :, :].contiguous()
-        #### extract LR features
-        L1_fea = conv(x.view(-1, C, H, W), self.conv_first, LRELU)
+        L1_fea = conv(frames, self.conv_first, LRELU)
         L1_fea = self.feature_extraction(L1_fea)
         L2_fea = conv(L1_fea, self.fea_L2_conv1, LRELU)
         L2_fea = conv(L2_fea, self.fea_L2_conv2, LRELU)
         L3_fea = conv(L2_fea, self.fea_L3_conv1, LRELU)
         L3_fea = conv(L3_fea, self.fea_L3_conv2, LRELU)
-        L1_fea = L1_fea.view(B, N, -1, H, W)
-        L2_fea = L2_fea.view(B, N, -1, H // 2, W // 2)
-        L3_fea = L3_fea.view(B, N, -1, H // 4, W // 4)
-        #### pcd align
+        return L1_fea, L2_fea, L3_fea
+
+    def align_fuse_reconstruct(self, L1_fea, L2_fea, L3_fea, x_center):
+        """Window part (EDVR_arch.py:291-320): PCD alignment of every frame to the centre one, TSA fusion,
+        reconstruction.  L*_fea are [B, N, nf, h, w]; x_center is the centre LR frame [B, C, H, W]."""
+        conv = RF.conv2d
+        B, N, _, H, W = L1_fea.shape
         ref_fea_l = [L1_fea[:, self.center].contiguous(), L2_fea[:, self.center].contiguous(),
                      L3_fea[:, self.center].contiguous()]
         aligned_fea = []
@@ -200,6 +200,18 @@ class _EDVRBase(nn.Module):
             out = conv(out, self.HRconv, LRELU)
             base = x_center
         return conv(out, self.conv_last, residual=base)
+
+    def forward(self, x):
+        B, N, C, H, W = x.size()  # N video frames
+        if H % 4 or W % 4:
+            raise RuntimeError('EDVR needs H and W divisible by 4 (got %dx%d)' % (H, W))
+        x = x.contiguous()
+        x_center = x[:, self.center, :, :, :].contiguous()
+        L1_fea, L2_fea, L3_fea = self.extract_features(x.view(-1, C, H, W))
+        L1_fea = L1_fea.view(B, N, -1, H, W)
+        L2_fea = L2_fea.view(B, N, -1, H // 2, W // 2)
+        L3_fea = L3_fea.view(B, N, -1, H // 4, W // 4)
+        return self.align_fuse_reconstruct(L1_fea, L2_fea, L3_fea, x_center)
 
 
 class EDVR(_EDVRBase):

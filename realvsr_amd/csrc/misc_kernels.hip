@@ -584,3 +584,39 @@ extern "C" int rvsr_gwloss_backward(const float* fa, const float* fbx, const flo
     hipLaunchKernelGGL(gw_bwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, fa, fbx, fby, gscalar, scale, gx, planes, H, W);
     CHECK_LAUNCH("gwloss_bwd");
 }
+
+// ---------------------------------------------------------------- YCbCr (planar f32) -> BGR uint8 (HWC)
+// Restates, operation for operation, what the reference's test script does on the host with numpy
+// (test_RealVSR_wi_GT.py:122-123): tensor2img(out_type=float32, reverse_channel=False) = clamp to [0, 1];
+// data/util.py:397-416 ycbcr2bgr on a float32 image: `img *= 255` in f32, matmul with the f64 matrix (f64
+// accumulation), `* 255.0 + offset`, `/ 255.` in f64, cast to f32; then clip, `* 255.` in f32, round half to even,
+// uint8.  Done on the GPU so a frame leaves as 3 bytes per pixel instead of 12.
+__global__ void ycbcr2bgr_u8_kernel(const float* __restrict__ ycc, unsigned char* __restrict__ bgr, size_t hw) {
+    const double M[3][3] = {{0.00456621, 0.00456621, 0.00456621}, {0.00791071, -0.00153632, 0.0}, {0.0, -0.00318811, 0.00625893}};
+    const double off[3] = {-276.836, 135.576, -222.921};
+    LOOP(i, hw) {
+        float s[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = ycc[(size_t)c * hw + i];
+            v = fminf(fmaxf(v, 0.f), 1.f);
+            s[c] = __fmul_rn(v, 255.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double d = __dmul_rn((double)s[0], M[0][j]);
+            d = __dadd_rn(d, __dmul_rn((double)s[1], M[1][j]));
+            d = __dadd_rn(d, __dmul_rn((double)s[2], M[2][j]));
+            d = __dadd_rn(__dmul_rn(d, 255.0), off[j]);
+            float r = (float)(d / 255.0);
+            r = fminf(fmaxf(r, 0.f), 1.f);
+            bgr[i * 3 + j] = (unsigned char)rintf(__fmul_rn(r, 255.f));
+        }
+    }
+}
+extern "C" int rvsr_ycbcr_to_bgr_u8(const float* ycc, unsigned char* bgr, int H, int W, void* stream) {
+    if (!ycc || !bgr || H <= 0 || W <= 0) FAIL(RVSR_ERR_BAD_ARG, "ycbcr_to_bgr_u8: null/empty argument");
+    const size_t hw = (size_t)H * W;
+    hipLaunchKernelGGL(ycbcr2bgr_u8_kernel, GRID_FOR(hw), dim3(256), 0, (hipStream_t)stream, ycc, bgr, hw);
+    CHECK_LAUNCH("ycbcr_to_bgr_u8");
+}

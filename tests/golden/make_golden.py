@@ -201,5 +201,50 @@ def main():
     save('losses', **arrs)
 
 
+def main_infer():
+    """infer.npz: the steps either side of the path at test time:
+    index_generation tables, flip x4 ensemble of a tiny EDVR_NoUp, YCbCr -> BGR uint8 quantisation
+    (test_RealVSR_wi_GT.py:114-123)."""
+    EDVR_arch, loss_mod, util, dc = import_reference()
+    import data.util as data_util
+    arrs = {}
+    # ---- index_generation (data/util.py:169-214): every centre for a few (max_n, N), all four modes
+    rows = []
+    modes = ['replicate', 'reflection', 'new_info', 'circle']
+    for mi, mode in enumerate(modes):
+        for max_n in (5, 7, 12, 30):
+            for N in (3, 5, 7):
+                if N > max_n:
+                    continue
+                for crt in range(max_n):
+                    rows.append([mi, max_n, N, crt] + data_util.index_generation(crt, max_n, N, padding=mode) + [-1] * (7 - N))
+    arrs['index_table'] = np.array(rows, dtype=np.int32)
+    # ---- colour conversion + quantisation exactly as the test script does it
+    rng = np.random.RandomState(5)
+    ycc = (rng.rand(3, 24, 40).astype(np.float32) * 1.3 - 0.15)       # values outside [0, 1] on purpose
+    ycc[:, :2, :] = np.array([16, 128, 128], np.float32)[:, None, None] / 255.  # black
+    ycc[:, 2:4, :] = np.array([235, 128, 128], np.float32)[:, None, None] / 255.  # white
+    t = torch.from_numpy(ycc.copy())
+    out = util.tensor2img(t, out_type=np.float32, reverse_channel=False)
+    img = (np.clip(data_util.ycbcr2bgr(out), 0, 1) * 255.).round().astype(np.uint8)
+    arrs['ycc'] = ycc
+    arrs['bgr_u8'] = img
+    # ---- flip x4 self-ensemble through the reference's own helper on a tiny EDVR_NoUp
+    torch.manual_seed(3)
+    net = EDVR_arch.EDVR_NoUp(nf=64, nc=3, nframes=3, groups=8, front_RBs=1, back_RBs=1, center=None, predeblur=False,
+                              HR_in=False, w_TSA=True)
+    fill_state_dict(net, 123)
+    net.eval()
+    x = torch.rand(1, 3, 3, 16, 24)
+    arrs['flip_x'] = x.numpy()
+    arrs['flip_single'] = util.single_forward(net, x).numpy()
+    arrs['flip_x4'] = util.flipx4_forward(net, x).numpy()
+    save('infer', **arrs)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'infer':
+        main_infer()
+    else:
+        main()
+        main_infer()
