@@ -126,16 +126,8 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
             om = RF.conv2d(feat, self.conv_offset_mask)
             return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                self.deformable_groups, act, slope)
-        # general geometry: explicit chunk / cat / sigmoid, dense-offset operator
-        out = torch.nn.functional.conv2d(feat, self.conv_offset_mask.weight, self.conv_offset_mask.bias,
-                                         self.conv_offset_mask.stride, self.conv_offset_mask.padding)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        out = modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                                    self.dilation, self.groups, self.deformable_groups)
-        if act == RF.ACT_RELU:
-            out = torch.relu(out)
-        elif act == RF.ACT_LRELU:
-            out = torch.nn.functional.leaky_relu(out, slope)
-        return out
+        # Everything the reference's architectures instantiate (EDVR_arch.py:73-74, TDAN_arch.py:29-41) is 3x3, groups=1,
+        # "same" padding.  Other geometries have no HIP kernel here and there is deliberately no library fallback.
+        raise RuntimeError('ModulatedDeformConvPack: only 3x3 / groups=1 / padding=dilation is implemented on the '
+                           'MI355X path (got kernel %s, groups %d, padding %s, dilation %s)'
+                           % (self.kernel_size, self.groups, self.padding, self.dilation))

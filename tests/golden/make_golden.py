@@ -242,9 +242,35 @@ def main_infer():
     save('infer', **arrs)
 
 
+def main_tdan():
+    """tdan.npz: the reference's TDAN (models/archs/TDAN_arch.py) with the oracle DCN: output and a few
+    gradients for two small configurations (scale 1 as RealVSR uses it, and scale 2 for the Upsampler path)."""
+    import_reference()
+    import models.archs.TDAN_arch as TDAN_arch
+    arrs = {}
+    for tag, scale, nframes, (H, W) in (('s1', 1, 3, (12, 20)), ('s2', 2, 3, (8, 12))):
+        torch.manual_seed(11)
+        net = TDAN_arch.TDAN(channel=3, nframes=nframes, scale=scale, nf=64, nb_f=1, nb_b=1, groups=8)
+        fill_state_dict(net, 31, offset_std=0.05)
+        x = torch.rand(1, nframes, 3, H, W, generator=torch.Generator().manual_seed(12))
+        out = net(x)
+        gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(13))
+        out.backward(gout)
+        arrs[tag + '.x'] = x.numpy()
+        arrs[tag + '.out'] = out.detach().numpy()
+        arrs[tag + '.gout'] = gout.numpy()
+        for k in ('align.deform_conv_1.weight', 'align.deform_conv.conv_offset_mask.weight', 'align.bottle_neck.weight',
+                  'align.initial_conv.bias', 'trunk.feature_extractor.0.weight', 'trunk.upsampler.1.weight'):
+            arrs[tag + '.grad.' + k] = dict(net.named_parameters())[k].grad.numpy().copy()
+        arrs[tag + '.keys'] = np.array(sorted(net.state_dict().keys()))
+    save('tdan', **arrs)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'infer':
-        main_infer()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('all', 'main'):
         main()
+    if which in ('all', 'infer'):
         main_infer()
+    if which in ('all', 'tdan'):
+        main_tdan()

@@ -121,3 +121,22 @@ def test_config1_vs_oracle_psnr(gemm_mode):
     print('PSNR-Y vs synthetic GT: build %.6f dB, oracle %.6f dB; build-vs-oracle %.2f dB'
           % (p_build, p_oracle, O.psnr_y_uint8(out, ref)))
     assert abs(p_build - p_oracle) <= 1e-3
+
+
+@pytest.mark.parametrize('tag,scale', [('s1', 1), ('s2', 2)])
+def test_tdan_fixture(gemm_mode, tag, scale):
+    """the reference's other consumer of the DCN operator, same weights (seeded fill)."""
+    TOL, TOL_G, _ = TOLS[gemm_mode]
+    from weights import fill_state_dict
+    from realvsr_amd.archs.TDAN_arch import TDAN
+    g = load_golden('tdan')
+    net = TDAN(channel=3, nframes=3, scale=scale, nf=64, nb_f=1, nb_b=1, groups=8)
+    fill_state_dict(net, 31, offset_std=0.05)
+    net = net.to(dev())
+    out = net(_t(g, tag + '.x'))
+    out.backward(_t(g, tag + '.gout'))
+    check(tag + ' out', out, torch.from_numpy(g[tag + '.out']), TOL)
+    params = dict(net.named_parameters())
+    for k in g:
+        if k.startswith(tag + '.grad.'):
+            gcheck(gemm_mode, k, params[k[len(tag) + 6:]].grad, torch.from_numpy(g[k]), TOL_G)

@@ -49,3 +49,11 @@ def test_driver_refuses_cpu_and_bad_shapes():
     r = infer.SlidingWindowRunner(_Net(), 5)
     with pytest.raises(RuntimeError):
         r(torch.zeros(4, 3, 10, 16))      # H not divisible by 4
+
+
+def test_tdan_state_dict_schema_matches_reference():
+    from realvsr_amd.archs.TDAN_arch import TDAN
+    g = load_golden('tdan')
+    for tag, scale in (('s1', 1), ('s2', 2)):
+        net = TDAN(channel=3, nframes=3, scale=scale, nf=64, nb_f=1, nb_b=1, groups=8)
+        assert sorted(net.state_dict().keys()) == [str(k) for k in g[tag + '.keys']]
