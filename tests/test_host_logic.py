@@ -67,5 +67,9 @@ def test_define_g():
                          'back_RBs': 10, 'w_TSA': False}}
     net = define_G(opt)
     assert isinstance(net, EDVR_NoUp) and net.center == 1 and isinstance(net.tsa_fusion, torch.nn.Conv2d)
+    from realvsr_amd.archs.TDAN_arch import TDAN
+    tdan = define_G({'scale': 1, 'network_G': {'which_model_G': 'TDAN', 'nf': 64, 'nc': 3, 'nframes': 3, 'nb_f': 1,
+                                               'nb_b': 1, 'groups': 8}})
+    assert isinstance(tdan, TDAN)
     with pytest.raises(NotImplementedError):
-        define_G({'network_G': {'which_model_G': 'TDAN'}})
+        define_G({'network_G': {'which_model_G': 'RCAN'}})
