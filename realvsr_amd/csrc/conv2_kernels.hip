@@ -835,6 +835,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     constexpr int NXI = 4;                  // X items per thread: 64 c x 6 rows x 5 octets = 1920 / 512 -> 3.75
     float4 gv[NGI][NGV], sv[ACT ? NGI : 1][NGV], xv[NXI][2];
     unsigned gok = 0, xok = 0;              // bit (i * 4 + k): float4 k of item i is inside the image
+    float bacc[NGI] = {0.f, 0.f};           // bias-gradient partial sums of this thread's two G items
 
     // per-thread item geometry is tile-independent: decode it once (the divisions / 64-bit products used to cost more
     // than the loads themselves: ~5.5 K cycles to issue 20 loads)
@@ -874,17 +875,22 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     const size_t img_g = GMODE == 0 ? (size_t)p.Co * H * W : (size_t)p.Co * H * W;  // elements per image of G (same count either way)
     const size_t img_x1 = (size_t)C1 * H * W, img_x2 = (size_t)(Ctot - C1) * H * W;
 
-    auto issue_loads = [&](int tile) {
+    // `part` < 0: everything at once (prologue).  Otherwise part 0..7 = one eighth of the tile's loads: the main loop
+    // issues one part per k-step of the MFMA phase so the requests trickle out under the matrix work instead of as one
+    // burst in front of it (the burst took ~5.5 K cycles to issue: the memory pipeline back-pressures).
+    // parts 0-3: X item `part`; parts 4, 5: G item 0, 1; parts 6, 7: nothing.
+    auto issue_loads = [&](int tile, int part) {
         const int b = tile / (p.nty * p.ntx);
         const int trem = tile - b * (p.nty * p.ntx);
         const int ty = trem / p.ntx, tx = trem - ty * p.ntx;
         const int y0 = ty * 4, x0 = tx * 32;
-        gok = 0;
-        xok = 0;
+        if (part < 0 || part == 4) gok = 0;
+        if (part <= 0) xok = 0;
         const float* gimg = p.g.p + (size_t)b * img_g;
         const float* simg = ACT ? p.g.act + (size_t)b * img_g : nullptr;
 #pragma unroll
         for (int i = 0; i < NGI; ++i) {
+            if (part >= 0 && part != 4 + i) continue;
             const int gy = y0 + g_row[i], gx = x0 + g_gx8[i];
             const bool ok = g_o[i] < p.Co && gy < H;
             if (GMODE == 0) {
@@ -913,6 +919,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         const float* x2img = p.x.b.p != nullptr ? p.x.b.p + (size_t)b * img_x2 : x1img;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
+            if (part >= 0 && part != i) continue;
             const int gy = y0 + x_row[i], gx = x0 + x_gx[i];
             const bool ok = x_live[i] && gy >= 0 && gy < H;
             const float* src = x_sec[i] ? x2img : x1img;
@@ -961,10 +968,10 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                     v[2 * k + 1] = okk ? e1 : 0.f;
                 }
             }
-            if (do_bias) {
-                const float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                atomicAdd(&bsum[ol], sm);
-            }
+            // bias gradient: a G item's output channel does not depend on the tile, so every thread keeps its own
+            // running sums and the workgroup reduces them once after the tile loop (LDS float atomics here cost
+            // ~117 LDS cycles per wave-instruction, twice per tile)
+            if (do_bias) bacc[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             bf16x8 h8, l8;
             split8(v, h8, l8);
             *reinterpret_cast<bf16x8*>(gs_hi + g_lds[i]) = h8;
@@ -992,7 +999,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     const int ntiles = p.B * p.nty * p.ntx;
     const int per = (ntiles + p.P - 1) / p.P;
     const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
-    if (t_begin < t_end) issue_loads(t_begin);
+    if (t_begin < t_end) issue_loads(t_begin, -1);
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int ti = tile - t_begin;
         if (ti < 6) STAMP(100 + ti * 5);
@@ -1000,11 +1007,14 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         if (ti < 6) STAMP(101 + ti * 5);
         __syncthreads();
         if (ti < 6) STAMP(102 + ti * 5);
-        if (tile + 1 < t_end) issue_loads(tile + 1);
         if (ti < 6) STAMP(103 + ti * 5);
+        const bool more = tile + 1 < t_end;
+        if (!m_live && more) issue_loads(tile + 1, -1);
         if (m_live) {
-#pragma unroll 2
+#pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
+                if (more) issue_loads(tile + 1, ks);
+                __builtin_amdgcn_sched_barrier(0);
                 const int row = ks >> 1, cb = (ks & 1) * 16 + 8 * hi;  // this lane's 8 pixels: row, cols cb..cb+7
                 const int goff = (m * 32 + lo) * WG2_GP + row * 64 + cb * 2;
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(gs_hi + goff);
@@ -1038,9 +1048,22 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             }
         }
     }
-    if (do_bias && tid < 64) {
-        const int o = mb * 64 + tid;
-        if (o < p.Co) p.bpart[(size_t)blockIdx.x * p.Co + o] = bsum[tid];
+    if (do_bias) {
+        // item i of thread t covers output channel (t + 512 i) >> 4: the 16 lanes of a row group share it
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+            float v = bacc[i];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if ((tid & 15) == 0) bsum[(tid + i * WG2_THREADS) >> 4] = v;   // one writer per channel
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int o = mb * 64 + tid;
+            if (o < p.Co) p.bpart[(size_t)blockIdx.x * p.Co + o] = bsum[tid];
+        }
     }
 }
 
