@@ -100,12 +100,15 @@ class TSA_Fusion(nn.Module):
         self.sAtt_add_1 = nn.Conv2d(nf, nf, 1, 1, bias=True)
         self.sAtt_add_2 = nn.Conv2d(nf, nf, 1, 1, bias=True)
 
-    def forward(self, aligned_fea):
+    def forward(self, aligned_fea, center_fea=None):
+        """aligned_fea: [B, N, C, H, W].  center_fea (optional, not in the reference signature): the tensor that was
+        stacked at index `center`; passing it avoids slicing the stack (a strided copy forward and a full-size
+        zero-fill + add in autograd's select backward)."""
         conv, up = RF.conv2d, RF.upsample_bilinear
         B, N, C, H, W = aligned_fea.size()  # N video frames
         aligned_fea = aligned_fea.contiguous()
         #### temporal attention
-        emb_ref = conv(aligned_fea[:, self.center], self.tAtt_2)
+        emb_ref = conv(aligned_fea[:, self.center] if center_fea is None else center_fea, self.tAtt_2)
         emb = conv(aligned_fea.view(-1, C, H, W), self.tAtt_1).view(B, N, -1, H, W)
         aligned_fea = RF.tsa_temporal(emb, emb_ref, aligned_fea)  # [B, N*C, H, W]
         #### fusion
@@ -174,20 +177,18 @@ class _EDVRBase(nn.Module):
         L3_fea = conv(L3_fea, self.fea_L3_conv2, LRELU)
         return L1_fea, L2_fea, L3_fea
 
-    def align_fuse_reconstruct(self, L1_fea, L2_fea, L3_fea, x_center):
+    def align_fuse_reconstruct(self, L1_l, L2_l, L3_l, x_center):
         """Window part (EDVR_arch.py:291-320): PCD alignment of every frame to the centre one, TSA fusion,
-        reconstruction.  L*_fea are [B, N, nf, h, w]; x_center is the centre LR frame [B, C, H, W]."""
+        reconstruction.  L*_l are lists of N per-frame feature tensors [B, nf, h, w] (contiguous); x_center is
+        the centre LR frame [B, C, H, W]."""
         conv = RF.conv2d
-        B, N, _, H, W = L1_fea.shape
-        ref_fea_l = [L1_fea[:, self.center].contiguous(), L2_fea[:, self.center].contiguous(),
-                     L3_fea[:, self.center].contiguous()]
-        aligned_fea = []
-        for i in range(N):
-            nbr_fea_l = [L1_fea[:, i].contiguous(), L2_fea[:, i].contiguous(), L3_fea[:, i].contiguous()]
-            aligned_fea.append(self.pcd_align(nbr_fea_l, ref_fea_l))
-        aligned_fea = torch.stack(aligned_fea, dim=1)  # [B, N, C, H, W]
+        N = len(L1_l)
+        B, _, H, W = L1_l[0].shape
+        ref_fea_l = [L1_l[self.center], L2_l[self.center], L3_l[self.center]]
+        aligned_l = [self.pcd_align([L1_l[i], L2_l[i], L3_l[i]], ref_fea_l) for i in range(N)]
+        aligned_fea = torch.stack(aligned_l, dim=1)  # [B, N, C, H, W]
         if self.w_TSA:
-            fea = self.tsa_fusion(aligned_fea)
+            fea = self.tsa_fusion(aligned_fea, center_fea=aligned_l[self.center])
         else:
             fea = conv(aligned_fea.view(B, -1, H, W), self.tsa_fusion)
         out = self.recon_trunk(fea)
@@ -205,13 +206,17 @@ class _EDVRBase(nn.Module):
         B, N, C, H, W = x.size()  # N video frames
         if H % 4 or W % 4:
             raise RuntimeError('EDVR needs H and W divisible by 4 (got %dx%d)' % (H, W))
-        x = x.contiguous()
         x_center = x[:, self.center, :, :, :].contiguous()
-        L1_fea, L2_fea, L3_fea = self.extract_features(x.view(-1, C, H, W))
-        L1_fea = L1_fea.view(B, N, -1, H, W)
-        L2_fea = L2_fea.view(B, N, -1, H // 2, W // 2)
-        L3_fea = L3_fea.view(B, N, -1, H // 4, W // 4)
-        return self.align_fuse_reconstruct(L1_fea, L2_fea, L3_fea, x_center)
+        # Frame-major batch for the per-frame stage: frame i of every window is then one contiguous block, so the
+        # per-frame feature tensors are views (unbind) and their gradients come back as ONE stack.  The reference's
+        # batch-major view + `[:, i]` slicing (EDVR_arch.py:291-303) costs, per slice and level, a full-size zero
+        # fill plus a full-size add in autograd's select backward (~4 ms per step at config 2).
+        xf = x.transpose(0, 1).contiguous().view(N * B, C, H, W)
+        L1_fea, L2_fea, L3_fea = self.extract_features(xf)
+        L1_l = L1_fea.view(N, B, -1, H, W).unbind(0)
+        L2_l = L2_fea.view(N, B, -1, H // 2, W // 2).unbind(0)
+        L3_l = L3_fea.view(N, B, -1, H // 4, W // 4).unbind(0)
+        return self.align_fuse_reconstruct(L1_l, L2_l, L3_l, x_center)
 
 
 class EDVR(_EDVRBase):

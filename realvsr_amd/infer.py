@@ -106,11 +106,9 @@ class SlidingWindowRunner(object):
         L1, L2, L3 = self._features(clip)
         outs = []
         for t in range(T):
-            idx = torch.tensor(index_generation(t, T, self.N, self.padding), device=clip.device)
-            outs.append(self.net.align_fuse_reconstruct(L1.index_select(0, idx).unsqueeze(0),
-                                                        L2.index_select(0, idx).unsqueeze(0),
-                                                        L3.index_select(0, idx).unsqueeze(0),
-                                                        clip[t:t + 1].contiguous()))
+            idx = index_generation(t, T, self.N, self.padding)
+            outs.append(self.net.align_fuse_reconstruct([L1[j:j + 1] for j in idx], [L2[j:j + 1] for j in idx],
+                                                        [L3[j:j + 1] for j in idx], clip[t:t + 1].contiguous()))
         return torch.cat(outs, 0)
 
     def __call__(self, clip):
