@@ -23,8 +23,10 @@
 __device__ unsigned long long rvsr_dbg_dcn[256];
 extern "C" int rvsr_debug_read_dcn(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_dcn), sizeof(unsigned long long) * 256); }
 #define DSTAMP(i) do { if (blockIdx.x == 77 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DSTAMP_W(i) do { if (blockIdx.x == 7 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DSTAMP(i) do {} while (0)
+#define DSTAMP_W(i) do {} while (0)
 #endif
 
 #define D2_R 3  // halo radius (pixels) of the LDS x tile beyond the 3x3 footprint
@@ -549,6 +551,7 @@ struct DcnBwdW2Params {
     float* part;   // [8P][Co][C][9]
     float* bpart;  // [8P][Co] or nullptr
     int P, nty;
+    int gvec;      // g.p / g.act 16-byte aligned: the gradient tile may be staged with 16-byte loads
 };
 
 __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params p) {
@@ -577,14 +580,44 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
 
     const int ntiles = d.B * p.nty * d.ntx;
     for (int tile = blockIdx.x; tile < ntiles; tile += p.P) {
+        const bool st_ = tile == blockIdx.x + 2 * p.P;  // third tile of this workgroup
+        if (st_) DSTAMP_W(160);
         const int b = tile / (p.nty * d.ntx);
         const int trem = tile - b * (p.nty * d.ntx);
         const int ty = trem / d.ntx, tx = trem - ty * d.ntx;
         const int y0 = ty * 4, x0 = tx * 32;
         const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;
-        // thread t stages pixel (t & 127) for output channels 4*(t >> 7) + 16*i + 0..3, four at a time (one batch of
-        // loads in flight: the 96 accumulator registers leave no room for more)
-        if (p.g.mode == 0) {  // (uniform)
+        if (p.g.mode == 0 && (d.Wo & 3) == 0 && p.gvec) {  // (uniform)
+            // 16-byte loads: item = (output channel, group of 4 pixels); 4 items per thread, all loads (value + act')
+            // in flight together.  Dword loads made this phase load-instruction-bound (~9 K cycles per tile).
+            float4 g4[4], a4[4];
+            bool ok4[4];
+            const float* ap = p.g.act != nullptr ? p.g.act : p.g.p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = tid + i * NT;
+                const int pg = item & 31, ol = item >> 5;
+                const int o = mb * 64 + ol, yy = y0 + (pg >> 3), xx = x0 + 4 * (pg & 7);
+                ok4[i] = o < d.Co && yy < d.Ho && xx < d.Wo;
+                const size_t idx = ok4[i] ? (((size_t)b * d.Co + o) * d.Ho + yy) * d.Wo + xx : 0;
+                g4[i] = *reinterpret_cast<const float4*>(p.g.p + idx);
+                a4[i] = *reinterpret_cast<const float4*>(ap + idx);
+            }
+            const bool has_act = p.g.act != nullptr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = tid + i * NT;
+                const int pg = item & 31, ol = item >> 5;
+                const float f0 = has_act ? (a4[i].x > 0.f ? 1.f : p.g.slope) : 1.f, f1 = has_act ? (a4[i].y > 0.f ? 1.f : p.g.slope) : 1.f;
+                const float f2 = has_act ? (a4[i].z > 0.f ? 1.f : p.g.slope) : 1.f, f3 = has_act ? (a4[i].w > 0.f ? 1.f : p.g.slope) : 1.f;
+                float* dst = gT + (4 * pg) * GP + ol;
+                dst[0] = ok4[i] ? g4[i].x * f0 : 0.f;
+                dst[GP] = ok4[i] ? g4[i].y * f1 : 0.f;
+                dst[2 * GP] = ok4[i] ? g4[i].z * f2 : 0.f;
+                dst[3 * GP] = ok4[i] ? g4[i].w * f3 : 0.f;
+            }
+        } else if (p.g.mode == 0) {  // (uniform)
+            // thread t stages pixel (t & 127) for output channels 4*(t >> 7) + 16*i + 0..3, four at a time
             const int px = tid & 127, og = tid >> 7;
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
@@ -602,8 +635,11 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
                 gT[px * GP + ol] = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
             }
         }
+        if (st_) DSTAMP_W(161);
         stage_x_tile<NT, 2, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
+        if (st_) DSTAMP_W(162);
         __syncthreads();
+        if (st_) DSTAMP_W(163);
         // column tile: item = (pixel, tap); 8 channels of the chunk share the sampling geometry.
         // (dy, dx, mask) of all of a thread's items are fetched first, unconditionally (clamped pixel).
         constexpr int NBI = (DCN_NPX * 9 + NT - 1) / NT;
@@ -620,6 +656,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
             b_dx[i] = offp[hw];
             b_m[i] = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + tap) * hw + pixc];
         }
+        if (st_) DSTAMP_W(164);
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
             const int it = tid + i * NT;
@@ -674,7 +711,9 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
 #pragma unroll
             for (int j = 0; j < 8; ++j) colT[px * CP + j * 9 + tap] = v[j];
         }
+        if (st_) DSTAMP_W(165);
         __syncthreads();
+        if (st_) DSTAMP_W(166);
 #pragma unroll 2
         for (int ks = 0; ks < 8; ++ks) {  // wave w: pixels 16w .. 16w+15
             const int px = wave * 16 + 2 * ks + hi;
@@ -686,7 +725,9 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
                 if (m1_live) acc[1][n] = mfma32(a1, bv, acc[1][n]);
             }
         }
+        if (st_) DSTAMP_W(167);
         __syncthreads();
+        if (st_) DSTAMP_W(168);
     }
 
     const int q = blockIdx.x * 8 + wave;
@@ -714,6 +755,7 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
     if (d.cpg % 8 != 0) return -1;
     DcnBwdW2Params p;
     p.d = d; p.g = g; p.part = part; p.bpart = bpart_or_null; p.P = P; p.nty = nty;
+    p.gvec = ((((uintptr_t)g.p) | ((uintptr_t)g.act)) & 15) == 0;
     constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
     const size_t lds = (size_t)16 * 2 * TR * TC + sizeof(float) * (DCN_NPX * 65 + DCN_NPX * 97);
     if (set_lds(dcn_bwdw2_kernel, lds)) return -2;

@@ -32,3 +32,10 @@ prev = t[100]
 for i in sorted(names, key=lambda i: t[i]):
     print('%-44s +%7d  (t=%d)' % (names[i], t[i] - prev, t[i] - t[100]))
     prev = t[i]
+print('--- dcn_bwdw2_kernel, third tile of one workgroup (8 waves, 128 px, one 8-channel group)')
+nm = {160: 'tile start', 161: 'gOut tile staged (4 batches of 4 loads)', 162: 'x tile staged', 163: 'barrier',
+      164: 'offsets/masks of 3 items loaded (issue)', 165: 'column tile built', 166: 'barrier', 167: '48 f32 MFMAs', 168: 'barrier'}
+prev = t[160]
+for i in sorted(nm):
+    print('%-44s +%7d' % (nm[i], t[i] - prev))
+    prev = t[i]
