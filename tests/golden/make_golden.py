@@ -266,8 +266,36 @@ def main_tdan():
     save('tdan', **arrs)
 
 
+def main_augment():
+    """augment.npz: the reference's cutblur / rgb / apply_augment (data/augments_video_allpair.py) under fixed numpy
+    seeds; 4-D images for cutblur (the shape its h/w indexing is written for) and 5-D clips for rgb."""
+    import_reference()
+    import data.augments_video_allpair as aug
+    arrs = {}
+    rs = np.random.RandomState(21)
+    a4, b4 = rs.rand(2, 3, 20, 28).astype(np.float32), rs.rand(2, 3, 20, 28).astype(np.float32)
+    a5, b5 = rs.rand(2, 3, 3, 12, 16).astype(np.float32), rs.rand(2, 3, 3, 12, 16).astype(np.float32)
+    arrs.update(a4=a4, b4=b4, a5=a5, b5=b5)
+    for seed in range(6):
+        np.random.seed(100 + seed)
+        o1, o2 = aug.cutblur(torch.from_numpy(a4.copy()), torch.from_numpy(b4.copy()), prob=1.0, alpha=0.7)
+        arrs['cutblur%d.1' % seed], arrs['cutblur%d.2' % seed] = o1.numpy(), o2.numpy()
+    for seed in range(3):
+        np.random.seed(200 + seed)
+        o1, o2 = aug.rgb(torch.from_numpy(a5.copy()), torch.from_numpy(b5.copy()), prob=1.0)
+        arrs['rgb%d.1' % seed], arrs['rgb%d.2' % seed] = o1.numpy().copy(), o2.numpy().copy()
+    for seed in range(6):
+        np.random.seed(300 + seed)
+        o1, o2 = aug.apply_augment(torch.from_numpy(a5.copy()), torch.from_numpy(b5.copy()), ['none', 'cutblur', 'rgb'],
+                                   [1.0, 1.0, 1.0], [1.0, 0.7, 1.0], mix_p=[0.2, 0.5, 0.3])
+        arrs['mix%d.1' % seed], arrs['mix%d.2' % seed] = o1.numpy().copy(), o2.numpy().copy()
+    save('augment', **arrs)
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('all', 'augment'):
+        main_augment()
     if which in ('all', 'main'):
         main()
     if which in ('all', 'infer'):

@@ -57,3 +57,27 @@ def test_tdan_state_dict_schema_matches_reference():
     for tag, scale in (('s1', 1), ('s2', 2)):
         net = TDAN(channel=3, nframes=3, scale=scale, nf=64, nb_f=1, nb_b=1, groups=8)
         assert sorted(net.state_dict().keys()) == [str(k) for k in g[tag + '.keys']]
+
+
+def test_augment_matches_reference_under_seeds():
+    """same numpy-RNG call order as data/augments_video_allpair.py -> same boxes/permutations."""
+    from realvsr_amd import augment
+    g = load_golden('augment')
+    t = lambda k: torch.from_numpy(g[k].copy())
+    for seed in range(6):
+        np.random.seed(100 + seed)
+        o1, o2 = augment.cutblur(t('a4'), t('b4'), prob=1.0, alpha=0.7)
+        assert np.array_equal(o1.numpy(), g['cutblur%d.1' % seed]) and np.array_equal(o2.numpy(), g['cutblur%d.2' % seed])
+    for seed in range(3):
+        np.random.seed(200 + seed)
+        o1, o2 = augment.rgb(t('a5'), t('b5'), prob=1.0)
+        assert np.array_equal(o1.numpy(), g['rgb%d.1' % seed]) and np.array_equal(o2.numpy(), g['rgb%d.2' % seed])
+    for seed in range(6):
+        np.random.seed(300 + seed)
+        o1, o2 = augment.apply_augment(t('a5'), t('b5'), ['none', 'cutblur', 'rgb'], [1.0, 1.0, 1.0], [1.0, 0.7, 1.0],
+                                       mix_p=[0.2, 0.5, 0.3])
+        assert np.array_equal(o1.numpy(), g['mix%d.1' % seed]) and np.array_equal(o2.numpy(), g['mix%d.2' % seed])
+    with pytest.raises(ValueError):
+        augment.cutblur(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 4))
+    with pytest.raises(ValueError):
+        augment.apply_augment(t('a5'), t('b5'), ['mixup'], [1.0], [1.0])
