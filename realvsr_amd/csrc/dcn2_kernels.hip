@@ -24,9 +24,11 @@ __device__ unsigned long long rvsr_dbg_dcn[256];
 extern "C" int rvsr_debug_read_dcn(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_dcn), sizeof(unsigned long long) * 256); }
 #define DSTAMP(i) do { if (blockIdx.x == 77 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define DSTAMP_W(i) do { if (blockIdx.x == 7 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DSTAMP_W3(i) do { if (blockIdx.x == 7 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn[(i) + 20] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DSTAMP(i) do {} while (0)
 #define DSTAMP_W(i) do {} while (0)
+#define DSTAMP_W3(i) do {} while (0)
 #endif
 
 #define D2_R 3  // halo radius (pixels) of the LDS x tile beyond the 3x3 footprint
@@ -749,6 +751,232 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw2_kernel(const DcnBwdW2Params 
     }
 }
 
+__global__ __launch_bounds__(512, 2) void dcn_bwdw3_kernel(const DcnBwdW2Params p) {
+    // bf16x3 variant of dcn_bwdw2_kernel: both GEMM operands are kept PIXEL-contiguous as bf16 hi/lo ([row][128 px],
+    // 272-byte row pitch), so a wave's 16 pixels are one k-step of v_mfma_f32_32x32x16_bf16 and the tile costs
+    // 18 MFMAs per wave instead of 48 exact-f32 ones at twice the cycles each (6.6 K of ~18 K cycles per tile).
+    constexpr int RP = 272, NT = 512;   // row pitch in bytes: 128 px x 2 B + 16 B pad (conflict-free 16-byte reads)
+    constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);                      // [2 quads][NPOS]
+    unsigned char* g_hi = reinterpret_cast<unsigned char*>(xt + 2 * NPOS);  // [64 o][RP]
+    unsigned char* g_lo = g_hi + 64 * RP;
+    unsigned char* c_hi = g_lo + 64 * RP;                                   // [96 n][RP]; row 72 = 1 (bias), 73.. = 0
+    unsigned char* c_lo = c_hi + 96 * RP;
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int mb = blockIdx.y, c0 = blockIdx.z * 8;
+    const bool m1_live = mb * 64 + 32 < d.Co;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int g = c0 / d.cpg;
+
+    for (int e = tid; e < (96 - DCN_KC) * DCN_NPX; e += NT) {
+        const int j = e / DCN_NPX, px = e - j * DCN_NPX;
+        reinterpret_cast<__bf16*>(c_hi + (DCN_KC + j) * RP)[px] = (__bf16)(j == 0 ? 1.f : 0.f);
+        reinterpret_cast<__bf16*>(c_lo + (DCN_KC + j) * RP)[px] = (__bf16)0.f;
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = zero16();
+
+    const int ntiles = d.B * p.nty * d.ntx;
+    for (int tile = blockIdx.x; tile < ntiles; tile += p.P) {
+        const bool st_ = tile == blockIdx.x + 2 * p.P;  // third tile of this workgroup
+        if (st_) DSTAMP_W3(160);
+        const int b = tile / (p.nty * d.ntx);
+        const int trem = tile - b * (p.nty * d.ntx);
+        const int ty = trem / d.ntx, tx = trem - ty * d.ntx;
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;
+        if (p.g.mode == 0 && (d.Wo & 3) == 0 && p.gvec) {  // (uniform)
+            // 16-byte loads: item = (output channel, group of 4 pixels); 4 items per thread, all loads (value + act')
+            // in flight together.  Dword loads made this phase load-instruction-bound (~9 K cycles per tile).
+            float4 g4[4], a4[4];
+            bool ok4[4];
+            const float* ap = p.g.act != nullptr ? p.g.act : p.g.p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = tid + i * NT;
+                const int pg = item & 31, ol = item >> 5;
+                const int o = mb * 64 + ol, yy = y0 + (pg >> 3), xx = x0 + 4 * (pg & 7);
+                ok4[i] = o < d.Co && yy < d.Ho && xx < d.Wo;
+                const size_t idx = ok4[i] ? (((size_t)b * d.Co + o) * d.Ho + yy) * d.Wo + xx : 0;
+                g4[i] = *reinterpret_cast<const float4*>(p.g.p + idx);
+                a4[i] = *reinterpret_cast<const float4*>(ap + idx);
+            }
+            const bool has_act = p.g.act != nullptr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = tid + i * NT;
+                const int pg = item & 31, ol = item >> 5;
+                const float f0 = has_act ? (a4[i].x > 0.f ? 1.f : p.g.slope) : 1.f, f1 = has_act ? (a4[i].y > 0.f ? 1.f : p.g.slope) : 1.f;
+                const float f2 = has_act ? (a4[i].z > 0.f ? 1.f : p.g.slope) : 1.f, f3 = has_act ? (a4[i].w > 0.f ? 1.f : p.g.slope) : 1.f;
+                const float v0 = ok4[i] ? g4[i].x * f0 : 0.f, v1 = ok4[i] ? g4[i].y * f1 : 0.f;
+                const float v2 = ok4[i] ? g4[i].z * f2 : 0.f, v3 = ok4[i] ? g4[i].w * f3 : 0.f;
+                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t h, l;
+                h[0] = (__bf16)v0; h[1] = (__bf16)v1; h[2] = (__bf16)v2; h[3] = (__bf16)v3;
+                l[0] = (__bf16)(v0 - (float)h[0]); l[1] = (__bf16)(v1 - (float)h[1]);
+                l[2] = (__bf16)(v2 - (float)h[2]); l[3] = (__bf16)(v3 - (float)h[3]);
+                *reinterpret_cast<bf16x4_t*>(g_hi + ol * RP + (4 * pg) * 2) = h;   // pixels 4pg .. 4pg+3 of row ol
+                *reinterpret_cast<bf16x4_t*>(g_lo + ol * RP + (4 * pg) * 2) = l;
+            }
+        } else if (p.g.mode == 0) {  // (uniform)
+            // thread t stages pixel (t & 127) for output channels 4*(t >> 7) + 16*i + 0..3, four at a time
+            const int px = tid & 127, og = tid >> 7;
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int ol = 16 * i + 4 * og;
+                float v4[4];
+                tview_get_plain<4>(p.g, b, mb * 64 + ol, y0 + (px >> 5), x0 + (px & 31), v4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 h = (__bf16)v4[j];
+                    reinterpret_cast<__bf16*>(g_hi + (ol + j) * RP)[px] = h;
+                    reinterpret_cast<__bf16*>(g_lo + (ol + j) * RP)[px] = (__bf16)(v4[j] - (float)h);
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int e = tid; e < 64 * DCN_NPX; e += NT) {
+                const int ol = e >> 7, px = e & 127;
+                const int o = mb * 64 + ol;
+                const float gv = o < d.Co ? tview_get(p.g, b, o, y0 + (px >> 5), x0 + (px & 31)) : 0.f;
+                const __bf16 h = (__bf16)gv;
+                reinterpret_cast<__bf16*>(g_hi + ol * RP)[px] = h;
+                reinterpret_cast<__bf16*>(g_lo + ol * RP)[px] = (__bf16)(gv - (float)h);
+            }
+        }
+        if (st_) DSTAMP_W3(161);
+        stage_x_tile<NT, 2, TR, TC>(xt, d, b, c0, ty0, tx0, tid);
+        if (st_) DSTAMP_W3(162);
+        __syncthreads();
+        if (st_) DSTAMP_W3(163);
+        // column tile: item = (pixel, tap); 8 channels of the chunk share the sampling geometry.
+        // (dy, dx, mask) of all of a thread's items are fetched first, unconditionally (clamped pixel).
+        constexpr int NBI = (DCN_NPX * 9 + NT - 1) / NT;
+        float b_dy[NBI], b_dx[NBI], b_m[NBI];
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int it_raw = tid + i * NT;
+            const int it = it_raw < DCN_NPX * 9 ? it_raw : 0;
+            const int px = it & 127, tap = it >> 7;
+            const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+            const size_t pixc = (oy < d.Ho && ox < d.Wo) ? (size_t)oy * d.Wo + ox : 0;
+            const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18 + 2 * tap) * hw + pixc;
+            b_dy[i] = offp[0];
+            b_dx[i] = offp[hw];
+            b_m[i] = d.mask[(size_t)b * d.mask_bs + (size_t)(g * 9 + tap) * hw + pixc];
+        }
+        if (st_) DSTAMP_W3(164);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int it = tid + i * NT;
+            if (it >= DCN_NPX * 9) continue;
+            const int px = it & 127, tap = it >> 7;
+            const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (oy < d.Ho && ox < d.Wo) {
+                const float dy = b_dy[i], dx = b_dx[i];
+                float m = b_m[i];
+                if (d.mask_logit) m = 1.f / (1.f + __expf(-m));
+                const float y = (float)(oy * d.stride - d.pad + (tap / 3) * d.dil) + dy;
+                const float x = (float)(ox * d.stride - d.pad + (tap % 3) * d.dil) + dx;
+                if (y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W) {
+                    const float fy = floorf(y), fx = floorf(x);
+                    const int yi = (int)fy, xi = (int)fx;
+                    const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+                    const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                    const float w00 = (vy0 && vx0) ? hy * hx : 0.f, w01 = (vy0 && vx1) ? hy * lx : 0.f;
+                    const float w10 = (vy1 && vx0) ? ly * hx : 0.f, w11 = (vy1 && vx1) ? ly * lx : 0.f;
+                    const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1;
+                    const int cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                    const int r0 = cy0 - ty0, r1 = cy1 - ty0, s0 = cx0 - tx0, s1 = cx1 - tx0;
+                    if (r0 >= 0 && r1 < TR && s0 >= 0 && s1 < TC) {
+                        const int p00 = r0 * TC + s0, p01 = r0 * TC + s1, p10 = r1 * TC + s0, p11 = r1 * TC + s1;
+                        const float4 a00 = xt[p00], b00 = xt[NPOS + p00], a01 = xt[p01], b01 = xt[NPOS + p01];
+                        const float4 a10 = xt[p10], b10 = xt[NPOS + p10], a11 = xt[p11], b11 = xt[NPOS + p11];
+                        v[0] = w00 * a00.x + w01 * a01.x + w10 * a10.x + w11 * a11.x;
+                        v[1] = w00 * a00.y + w01 * a01.y + w10 * a10.y + w11 * a11.y;
+                        v[2] = w00 * a00.z + w01 * a01.z + w10 * a10.z + w11 * a11.z;
+                        v[3] = w00 * a00.w + w01 * a01.w + w10 * a10.w + w11 * a11.w;
+                        v[4] = w00 * b00.x + w01 * b01.x + w10 * b10.x + w11 * b11.x;
+                        v[5] = w00 * b00.y + w01 * b01.y + w10 * b10.y + w11 * b11.y;
+                        v[6] = w00 * b00.z + w01 * b01.z + w10 * b10.z + w11 * b11.z;
+                        v[7] = w00 * b00.w + w01 * b01.w + w10 * b10.w + w11 * b11.w;
+                    } else {
+                        const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                        const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (c0 + j < d.C) {
+                                const float* q = pl + (size_t)j * HW;
+                                v[j] = w00 * q[i00] + w01 * q[i01] + w10 * q[i10] + w11 * q[i11];
+                            }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= m;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 h = (__bf16)v[j];
+                reinterpret_cast<__bf16*>(c_hi + (j * 9 + tap) * RP)[px] = h;
+                reinterpret_cast<__bf16*>(c_lo + (j * 9 + tap) * RP)[px] = (__bf16)(v[j] - (float)h);
+            }
+        }
+        if (st_) DSTAMP_W3(165);
+        __syncthreads();
+        if (st_) DSTAMP_W3(166);
+        {   // wave w: pixels 16w .. 16w+15 = one k-step; lane (row lo, k-octet hi) reads pixels 16w + 8hi .. +7
+            const int koff = (wave * 16 + 8 * hi) * 2;
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(g_hi + (m * 32 + lo) * RP + koff);
+                al[m] = *reinterpret_cast<const bf16x8*>(g_lo + (m * 32 + lo) * RP + koff);
+            }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(c_hi + (n * 32 + lo) * RP + koff);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(c_lo + (n * 32 + lo) * RP + koff);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (m == 1 && !m1_live) continue;
+                    acc[m][n] = mfma_bf16(ah[m], bh, acc[m][n]);
+                    acc[m][n] = mfma_bf16(ah[m], bl, acc[m][n]);
+                    acc[m][n] = mfma_bf16(al[m], bh, acc[m][n]);
+                }
+            }
+        }
+        if (st_) DSTAMP_W3(167);
+        __syncthreads();
+        if (st_) DSTAMP_W3(168);
+    }
+
+    const int q = blockIdx.x * 8 + wave;
+    const int K = d.C * 9;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int kr = n * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mb * 64 + m * 32 + drow(r, hi);
+                if (o >= d.Co) continue;
+                const int kg = c0 * 9 + kr;
+                if (kr < DCN_KC && kg < K) p.part[((size_t)q * d.Co + o) * K + kg] = acc[m][n][r];
+                if (kr == DCN_KC && p.bpart != nullptr && blockIdx.z == 0) p.bpart[(size_t)q * d.Co + o] = acc[m][n][r];
+            }
+        }
+    }
+}
+
 // returns the number of partials written (8 * P), or -1 if the geometry is not covered
 int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* bpart_or_null, int P, int nty, int gy, int gz,
                           hipStream_t st) {
@@ -757,6 +985,12 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
     p.d = d; p.g = g; p.part = part; p.bpart = bpart_or_null; p.P = P; p.nty = nty;
     p.gvec = ((((uintptr_t)g.p) | ((uintptr_t)g.act)) & 15) == 0;
     constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    if (rvsr_g_gemm_mode == 0) {  // bf16x3
+        const size_t lds3 = (size_t)16 * 2 * TR * TC + (size_t)2 * (64 + 96) * 272;
+        if (set_lds(dcn_bwdw3_kernel, lds3)) return -2;
+        hipLaunchKernelGGL(dcn_bwdw3_kernel, dim3(P, gy, gz), dim3(512), lds3, st, p);
+        return 8 * P;
+    }
     const size_t lds = (size_t)16 * 2 * TR * TC + sizeof(float) * (DCN_NPX * 65 + DCN_NPX * 97);
     if (set_lds(dcn_bwdw2_kernel, lds)) return -2;
     hipLaunchKernelGGL(dcn_bwdw2_kernel, dim3(P, gy, gz), dim3(512), lds, st, p);
