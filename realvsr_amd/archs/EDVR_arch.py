@@ -187,10 +187,16 @@ class _EDVRBase(nn.Module):
         ref_fea_l = [L1_l[self.center], L2_l[self.center], L3_l[self.center]]
         aligned_l = [self.pcd_align([L1_l[i], L2_l[i], L3_l[i]], ref_fea_l) for i in range(N)]
         aligned_fea = torch.stack(aligned_l, dim=1)  # [B, N, C, H, W]
+        return self._fuse_reconstruct(aligned_fea, aligned_l[self.center], x_center)
+
+    def _fuse_reconstruct(self, aligned_fea, center_fea, x_center):
+        """TSA fusion (or the 1x1 fusion conv) + reconstruction on aligned features [B, N, C, H, W]."""
+        conv = RF.conv2d
+        B, N, _, H, W = aligned_fea.shape
         if self.w_TSA:
-            fea = self.tsa_fusion(aligned_fea, center_fea=aligned_l[self.center])
+            fea = self.tsa_fusion(aligned_fea, center_fea=center_fea)
         else:
-            fea = conv(aligned_fea.view(B, -1, H, W), self.tsa_fusion)
+            fea = conv(aligned_fea.reshape(B, -1, H, W), self.tsa_fusion)
         out = self.recon_trunk(fea)
         if self.upscale:
             out = conv(out, self.upconv1, LRELU, pixel_shuffle=True)
@@ -207,16 +213,20 @@ class _EDVRBase(nn.Module):
         if H % 4 or W % 4:
             raise RuntimeError('EDVR needs H and W divisible by 4 (got %dx%d)' % (H, W))
         x_center = x[:, self.center, :, :, :].contiguous()
-        # Frame-major batch for the per-frame stage: frame i of every window is then one contiguous block, so the
-        # per-frame feature tensors are views (unbind) and their gradients come back as ONE stack.  The reference's
-        # batch-major view + `[:, i]` slicing (EDVR_arch.py:291-303) costs, per slice and level, a full-size zero
-        # fill plus a full-size add in autograd's select backward (~4 ms per step at config 2).
+        # Frame-major batch: frame i of every window is one contiguous block of the [N*B, ...] feature tensors.  The
+        # reference loops over the N frames and slices `[:, i]` out of a batch-major view (EDVR_arch.py:291-303);
+        # PCD_Align shares its weights across frames, so here all N alignments run as ONE call on the N*B batch
+        # (neighbour features = the feature tensors themselves, reference features = the centre block repeated):
+        # per-sample arithmetic is unchanged, the kernels are 5x larger (fewer tail waves, 5x fewer launches and
+        # weight packs) and autograd sees no per-frame slices (each `[:, i]` costs a full-size zero fill and add in
+        # select-backward).
         xf = x.transpose(0, 1).contiguous().view(N * B, C, H, W)
-        L1_fea, L2_fea, L3_fea = self.extract_features(xf)
-        L1_l = L1_fea.view(N, B, -1, H, W).unbind(0)
-        L2_l = L2_fea.view(N, B, -1, H // 2, W // 2).unbind(0)
-        L3_l = L3_fea.view(N, B, -1, H // 4, W // 4).unbind(0)
-        return self.align_fuse_reconstruct(L1_l, L2_l, L3_l, x_center)
+        nbr_l = list(self.extract_features(xf))
+        ref_l = [f.view(N, B, *f.shape[1:])[self.center].repeat(N, 1, 1, 1) for f in nbr_l]
+        aligned = self.pcd_align(nbr_l, ref_l)                       # [N*B, nf, H, W], frame-major
+        aligned_nb = aligned.view(N, B, -1, H, W)
+        aligned_fea = aligned_nb.transpose(0, 1).contiguous()        # [B, N, nf, H, W] (what torch.stack(dim=1) built)
+        return self._fuse_reconstruct(aligned_fea, aligned_nb[self.center], x_center)
 
 
 class EDVR(_EDVRBase):
