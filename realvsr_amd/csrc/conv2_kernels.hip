@@ -506,13 +506,18 @@ __global__ __launch_bounds__(512, 2) void conv_fwd3_kernel(const ConvFwdParams p
         bf16x8* ws = ws_base + buf * 2 * WVEC;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
+            // validity as AND masks computed once per item: a compare + v_cndmask per value goes through VCC and
+            // serialises the (single) staging wave of the SIMD
+            unsigned vm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vm[j] = j < nvalid[i] ? 0xffffffffu : 0u;
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float x = ACT_IN ? vin[i][j][e] * (ain[i][j][e] > 0.f ? 1.f : va.slope) : vin[i][j][e];
-                    v[j] = j < nvalid[i] ? x : 0.f;
+                    v[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & vm[j]);
                 }
                 bf16x8 h8, l8;
                 split8(v, h8, l8);
