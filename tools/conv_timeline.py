@@ -12,19 +12,23 @@ buf = (ctypes.c_ulonglong * 256)()
 print('rc', L.rvsr_debug_read(buf))
 t = list(buf)
 names = {0: 'tile start'}
-V3 = os.environ.get('RVSR_CONV_FWD', '3') != '2'
+V3 = os.environ.get('RVSR_CONV_FWD', '5') != '2'
+V5 = os.environ.get('RVSR_CONV_FWD', '5') == '5'
 if V3:
     # conv_fwd3_kernel: stamps of the last 8 slots of workgroup 77, wave 0 (group A: even slots MFMA, odd slots staging)
     names = {}
     for sl in range(8):
-        kind = 'mfma(+epilogue)' if sl % 2 == 0 else 'commit+issue'
+        kind = ('mfma + staging slices' if V5 else ('mfma(+epilogue)' if sl % 2 == 0 else 'commit+issue'))
         names[1 + 3 * sl] = 'slot%d start' % sl
         names[2 + 3 * sl] = 'slot%d %s done' % (sl, kind)
         names[3 + 3 * sl] = 'slot%d barrier passed' % sl
-        if sl % 2:
+        if sl % 2 and not V5:
             names[40 + 2 * sl] = 'slot%d   loads landed' % sl
             names[41 + 2 * sl] = 'slot%d   committed to LDS' % sl
     print('workgroup 77: %d stages, kernel start -> end %d ticks (%.0f per stage)' % (t[62], t[61] - t[60], (t[61] - t[60]) / max(t[62], 1)))
+    if V5:
+        print('stage Q-3 per wave: loop time after the common barrier release:', [int(t[70 + w] - t[80 + w]) for w in range(8)])
+        print('stage Q-4 loop-end skew per wave:', [int(t[90 + w] - min(t[90:98])) for w in range(8)])
     order = sorted(names, key=lambda i: t[i])
     prev = t[order[0]]
     for i in order:
