@@ -321,6 +321,8 @@ struct DcnBwdIn2Params {
     float* goff;
     float* gmask;
     size_t goff_bs, gmask_bs;
+    int o_base, o_cnt;  // dcn_bwdin3 only: the pass covers output channels o_base .. o_base + o_cnt - 1 (o_cnt <= 64)
+    int accum;          // dcn_bwdin3 only: a later pass of the same call: add to grad_offset / grad_mask instead of overwriting
 };
 
 template <int TH, int NK>
@@ -1019,7 +1021,8 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
 #define D3_TH 8
 
 template <int NK>
-__global__ void pack_weights_bwd3_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int C, int nchunks) {
+__global__ void pack_weights_bwd3_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int o_base, int o_cnt, int C,
+                                         int nchunks) {
     // packed[chunk][mt (3)][part][ooct (2*NK)][row (32)][8 o];  row -> tap = 4*mt + (row >> 3), c = 8*chunk + (row & 7)
     const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1032,8 +1035,8 @@ __global__ void pack_weights_bwd3_kernel(const float* __restrict__ w, bf16x8* __
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int o = 8 * ooct + j;
-            v[j] = (tap < 9 && c < C && o < Co) ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+            const int ol = 8 * ooct + j;
+            v[j] = (tap < 9 && c < C && ol < o_cnt) ? w[((size_t)(o_base + ol) * C + c) * 9 + tap] : 0.f;
         }
         bf16x8 hi, lo;
         split8(v, hi, lo);
@@ -1105,12 +1108,15 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
         float v[8];
+        const int ol0 = 8 * (2 * ks + hi);  // first channel of this lane's octet inside the pass
         if (p.g.mode == 0) {  // (uniform)
-            tview_get_plain<8>(p.g, b, 8 * (2 * ks + hi), oy, ox, v);
+            tview_get_plain<8>(p.g, b, p.o_base + ol0, oy, ox, v);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tview_get(p.g, b, 8 * (2 * ks + hi) + j, oy, ox);
+            for (int j = 0; j < 8; ++j) v[j] = tview_get(p.g, b, p.o_base + ol0 + j, oy, ox);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ol0 + j < p.o_cnt ? v[j] : 0.f;
         split8(v, gh[ks], gl[ks]);
     }
     DSTAMP(101);
@@ -1288,7 +1294,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
                     if (d.mask_logit) gm_s *= m * (1.f - m);
                     float* go_ = p.goff + (size_t)b * p.goff_bs + (size_t)(g * 18 + 2 * tap) * hw + pix;
                     float* gk = p.gmask + (size_t)b * p.gmask_bs + (size_t)(g * 9 + tap) * hw + pix;
-                    if (c0 % d.cpg == 0) {
+                    if (c0 % d.cpg == 0 && !p.accum) {
                         go_[0] = gy_s;
                         go_[hw] = gx_s;
                         gk[0] = gm_s;
@@ -1331,7 +1337,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     DSTAMP(130);
 }
 
-static int nk_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : (Co <= 64 ? 4 : 8)); }
+static int nk_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : 4); }  // per pass of <= 64 output channels
 size_t rvsr_dcn_bwdin3_workspace_bytes(int Co, int C) { return (size_t)((C + 7) / 8) * 3 * 2 * (2 * nk_of(Co)) * 32 * 16; }
 
 template <int NK>
@@ -1340,7 +1346,7 @@ static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* wo
     const int nchunks = (d.C + 7) / 8;
     const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
     hipLaunchKernelGGL(pack_weights_bwd3_kernel<NK>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight,
-                       (bf16x8*)workspace, d.Co, d.C, nchunks);
+                       (bf16x8*)workspace, p.o_base, p.o_cnt, d.C, nchunks);
     constexpr int TR = D3_TH + D3_PR - 1, PPOS = D3_PR * D3_TC;
     const size_t lds = (size_t)16 * (2 * TR * D3_TC + D3_TH * 2 * PPOS + 3 * 2 * (2 * NK) * 32) + (size_t)4 * D3_TH * 2 * PPOS;
     auto k = dcn_bwdin3_kernel<NK>;
@@ -1354,15 +1360,26 @@ static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* wo
 
 int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st) {
-    // Co > 64 would need a 49 KB weight block on top of the private windows: exceeds 160 KB of LDS -> v2 kernel
-    if (d.cpg % 8 != 0 || d.Co > 64 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
+    // More than 64 output channels would need a 49 KB weight block on top of the private windows (> 160 KB of LDS) and
+    // 64 more registers of gOut fragments: they are handled as passes of <= 64 output channels.  Everything downstream
+    // of col_grad = W^T gOut is linear in it, so the passes simply add up (grad_input through the atomics it uses anyway,
+    // grad_offset / grad_mask with `accum`); the sampling work is repeated per pass (nf = 128: 2 passes, still ~2.5x
+    // faster than the LDS-atomic dcn_bwdin2 path).
+    if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin3_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     DcnBwdIn2Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
-    switch (nk_of(d.Co)) {
-        case 1: return launch_bwdin3<1>(p, weight, workspace, st);
-        case 2: return launch_bwdin3<2>(p, weight, workspace, st);
-        case 4: return launch_bwdin3<4>(p, weight, workspace, st);
-        default: return launch_bwdin3<8>(p, weight, workspace, st);
+    for (int ob = 0; ob < d.Co; ob += 64) {
+        p.o_base = ob;
+        p.o_cnt = d.Co - ob < 64 ? d.Co - ob : 64;
+        p.accum = ob > 0;
+        int rc;
+        switch (nk_of(p.o_cnt)) {
+            case 1: rc = launch_bwdin3<1>(p, weight, workspace, st); break;
+            case 2: rc = launch_bwdin3<2>(p, weight, workspace, st); break;
+            default: rc = launch_bwdin3<4>(p, weight, workspace, st); break;
+        }
+        if (rc != RVSR_OK) return rc;
     }
+    return RVSR_OK;
 }

@@ -59,6 +59,7 @@ SHAPES = [
     (1, 16, 16, 2, 11, 13, 2, 1, 1, 1.0, True),     # stride 2
     (1, 16, 16, 2, 11, 13, 1, 2, 2, 1.0, True),     # dilation 2
     (1, 8, 72, 1, 6, 34, 1, 1, 1, 1.0, True),       # Co > 64 (MT=4 path), dg 1
+    (1, 64, 80, 8, 10, 36, 1, 1, 1, 0.5, True),     # backward in two output-channel passes (64 + 16)
 ]
 
 
