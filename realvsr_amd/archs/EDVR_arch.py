@@ -22,6 +22,39 @@ from .. import functional as RF
 LRELU = RF.ACT_LRELU
 
 
+class Predeblur_ResNet_Pyramid(nn.Module):
+    """Pre-deblur pyramid (EDVR_arch.py:14-59): 3-level residual pyramid on every frame; same parameter names."""
+
+    def __init__(self, nf=128, HR_in=False):
+        super(Predeblur_ResNet_Pyramid, self).__init__()
+        self.HR_in = True if HR_in else False
+        if self.HR_in:
+            self.conv_first_1 = nn.Conv2d(3, nf, 3, 1, 1, bias=True)
+            self.conv_first_2 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+            self.conv_first_3 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+        else:
+            self.conv_first = nn.Conv2d(3, nf, 3, 1, 1, bias=True)
+        basic_block = functools.partial(arch_util.ResidualBlock_noBN, nf=nf)
+        for name in ('RB_L1_1', 'RB_L1_2', 'RB_L1_3', 'RB_L1_4', 'RB_L1_5', 'RB_L2_1', 'RB_L2_2', 'RB_L3_1'):
+            setattr(self, name, basic_block())
+        self.deblur_L2_conv = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+        self.deblur_L3_conv = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+
+    def forward(self, x):
+        conv, up = RF.conv2d, RF.upsample_bilinear
+        if self.HR_in:
+            L1_fea = conv(conv(conv(x, self.conv_first_1, LRELU), self.conv_first_2, LRELU), self.conv_first_3, LRELU)
+        else:
+            L1_fea = conv(x, self.conv_first, LRELU)
+        L2_fea = conv(L1_fea, self.deblur_L2_conv, LRELU)
+        L3_fea = conv(L2_fea, self.deblur_L3_conv, LRELU)
+        L3_fea = up(self.RB_L3_1(L3_fea), 2)
+        L2_fea = self.RB_L2_1(L2_fea) + L3_fea
+        L2_fea = up(self.RB_L2_2(L2_fea), 2)
+        L1_fea = self.RB_L1_2(self.RB_L1_1(L1_fea)) + L2_fea
+        return self.RB_L1_5(self.RB_L1_4(self.RB_L1_3(L1_fea)))
+
+
 class PCD_Align(nn.Module):
     """Alignment module using Pyramid, Cascading and Deformable convolution, 3 pyramid levels."""
 
@@ -133,18 +166,24 @@ class _EDVRBase(nn.Module):
     def __init__(self, nf=64, nc=3, nframes=5, groups=8, front_RBs=5, back_RBs=10, center=None, predeblur=False,
                  HR_in=False, w_TSA=True):
         super(_EDVRBase, self).__init__()
-        if predeblur or HR_in:
-            raise NotImplementedError('predeblur / HR_in branches are used by no shipped RealVSR config and are '
-                                      'not part of the MI355X hot path')
         self.nf = nf
         self.nc = nc
         self.center = nframes // 2 if center is None else center
-        self.is_predeblur = False
-        self.HR_in = False
+        # EDVR_NoUp stores these two flags but never acts on them (EDVR_arch.py:330-331, 359-363)
+        self.is_predeblur = True if predeblur else False
+        self.HR_in = True if HR_in else False
         self.w_TSA = w_TSA
         ResidualBlock_noBN_f = functools.partial(arch_util.ResidualBlock_noBN, nf=nf)
         #### extract features (for each frame)
-        self.conv_first = nn.Conv2d(nc, nf, 3, 1, 1, bias=True)
+        if self.upscale and self.is_predeblur:
+            self.pre_deblur = Predeblur_ResNet_Pyramid(nf=nf, HR_in=self.HR_in)
+            self.conv_1x1 = nn.Conv2d(nf, nf, 1, 1, bias=True)
+        elif self.upscale and self.HR_in:
+            self.conv_first_1 = nn.Conv2d(nc, nf, 3, 1, 1, bias=True)
+            self.conv_first_2 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+            self.conv_first_3 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
+        else:
+            self.conv_first = nn.Conv2d(nc, nf, 3, 1, 1, bias=True)
         self.feature_extraction = arch_util.make_layer(ResidualBlock_noBN_f, front_RBs)
         self.fea_L2_conv1 = nn.Conv2d(nf, nf, 3, 2, 1, bias=True)
         self.fea_L2_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
@@ -169,7 +208,12 @@ class _EDVRBase(nn.Module):
         L2/L3 pyramid convs on a [M, C, H, W] stack of frames.  It does not depend on which window a frame is in,
         which is what the sliding-window driver (realvsr_amd/infer.py) exploits."""
         conv = RF.conv2d
-        L1_fea = conv(frames, self.conv_first, LRELU)
+        if self.upscale and self.is_predeblur:      # EDVR_arch.py:264-268
+            L1_fea = conv(self.pre_deblur(frames), self.conv_1x1)
+        elif self.upscale and self.HR_in:           # :270-274: two stride-2 convs bring HR frames to the LR grid
+            L1_fea = conv(conv(conv(frames, self.conv_first_1, LRELU), self.conv_first_2, LRELU), self.conv_first_3, LRELU)
+        else:
+            L1_fea = conv(frames, self.conv_first, LRELU)
         L1_fea = self.feature_extraction(L1_fea)
         L2_fea = conv(L1_fea, self.fea_L2_conv1, LRELU)
         L2_fea = conv(L2_fea, self.fea_L2_conv2, LRELU)
@@ -210,7 +254,7 @@ class _EDVRBase(nn.Module):
             out = conv(out, self.upconv1, LRELU, pixel_shuffle=True)
             out = conv(out, self.upconv2, LRELU, pixel_shuffle=True)
             out = conv(out, self.HRconv, LRELU)
-            base = RF.upsample_bilinear(x_center, 4)
+            base = x_center if self.HR_in else RF.upsample_bilinear(x_center, 4)   # EDVR_arch.py:314-317
         else:
             out = conv(out, self.HRconv, LRELU)
             base = x_center
@@ -218,8 +262,9 @@ class _EDVRBase(nn.Module):
 
     def forward(self, x):
         B, N, C, H, W = x.size()  # N video frames
-        if H % 4 or W % 4:
-            raise RuntimeError('EDVR needs H and W divisible by 4 (got %dx%d)' % (H, W))
+        hr = self.upscale and self.HR_in
+        if H % (16 if hr else 4) or W % (16 if hr else 4):
+            raise RuntimeError('EDVR needs H and W divisible by %d (got %dx%d)' % (16 if hr else 4, H, W))
         x_center = x[:, self.center, :, :, :].contiguous()
         # Frame-major batch: frame i of every window is one contiguous block of the [N*B, ...] feature tensors.  The
         # reference loops over the N frames and slices `[:, i]` out of a batch-major view (EDVR_arch.py:291-303);
@@ -230,6 +275,8 @@ class _EDVRBase(nn.Module):
         # select-backward).
         xf = x.transpose(0, 1).contiguous().view(N * B, C, H, W)
         nbr_l = list(self.extract_features(xf))
+        if hr:
+            H, W = H // 4, W // 4
         ref_l = [f.view(N, B, *f.shape[1:])[self.center].repeat(N, 1, 1, 1) for f in nbr_l]
         aligned = self.pcd_align(nbr_l, ref_l)                       # [N*B, nf, H, W], frame-major
         aligned_nb = aligned.view(N, B, -1, H, W)

@@ -292,8 +292,33 @@ def main_augment():
     save('augment', **arrs)
 
 
+def main_predeblur():
+    """edvr_predeblur.npz: reference EDVR with predeblur=True (LR input), with HR_in=True, and with both: output and a
+    few gradients, seeded weights (weights.fill_state_dict)."""
+    EDVR_arch, loss_mod, util, dc = import_reference()
+    arrs = {}
+    for tag, kw, (H, W) in (('pre', dict(predeblur=True, HR_in=False), (16, 24)), ('hr', dict(predeblur=False, HR_in=True), (32, 48)),
+                            ('prehr', dict(predeblur=True, HR_in=True), (32, 32))):
+        torch.manual_seed(21)
+        net = EDVR_arch.EDVR(nf=64, nc=3, nframes=3, groups=8, front_RBs=1, back_RBs=1, center=None, w_TSA=False, **kw)
+        fill_state_dict(net, 41, offset_std=0.05)
+        x = torch.rand(1, 3, 3, H, W, generator=torch.Generator().manual_seed(22))
+        out = net(x)
+        gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(23))
+        out.backward(gout)
+        arrs[tag + '.x'], arrs[tag + '.out'], arrs[tag + '.gout'] = x.numpy(), out.detach().numpy(), gout.numpy()
+        params = dict(net.named_parameters())
+        for k in [n for n in params if n.startswith(('pre_deblur.RB_L3_1.conv1.w', 'pre_deblur.deblur_L2_conv.w', 'conv_1x1.w',
+                                                     'conv_first_2.w', 'pre_deblur.conv_first_3.b', 'conv_last.b'))]:
+            arrs[tag + '.grad.' + k] = params[k].grad.numpy().copy()
+        arrs[tag + '.keys'] = np.array(sorted(net.state_dict().keys()))
+    save('edvr_predeblur', **arrs)
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('all', 'predeblur'):
+        main_predeblur()
     if which in ('all', 'augment'):
         main_augment()
     if which in ('all', 'main'):

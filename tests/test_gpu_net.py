@@ -140,3 +140,23 @@ def test_tdan_fixture(gemm_mode, tag, scale):
     for k in g:
         if k.startswith(tag + '.grad.'):
             gcheck(gemm_mode, k, params[k[len(tag) + 6:]].grad, torch.from_numpy(g[k]), TOL_G)
+
+
+@pytest.mark.parametrize('tag,kw', [('pre', dict(predeblur=True, HR_in=False)), ('hr', dict(predeblur=False, HR_in=True)),
+                                    ('prehr', dict(predeblur=True, HR_in=True))])
+def test_edvr_predeblur_and_hr_in_fixture(gemm_mode, tag, kw):
+    """EDVR's pre-deblur pyramid and HR-input front ends (EDVR_arch.py:14-59, 264-274, 314-317) vs the reference."""
+    TOL, TOL_G, _ = TOLS[gemm_mode]
+    from weights import fill_state_dict
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    g = load_golden('edvr_predeblur')
+    net = EDVR(nf=64, nc=3, nframes=3, groups=8, front_RBs=1, back_RBs=1, w_TSA=False, **kw)
+    fill_state_dict(net, 41, offset_std=0.05)
+    net = net.to(dev())
+    out = net(_t(g, tag + '.x'))
+    out.backward(_t(g, tag + '.gout'))
+    check(tag + ' out', out, torch.from_numpy(g[tag + '.out']), TOL)
+    params = dict(net.named_parameters())
+    for k in g:
+        if k.startswith(tag + '.grad.'):
+            gcheck(gemm_mode, k, params[k[len(tag) + 6:]].grad, torch.from_numpy(g[k]), TOL_G)

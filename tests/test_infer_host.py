@@ -81,3 +81,12 @@ def test_augment_matches_reference_under_seeds():
         augment.cutblur(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 4))
     with pytest.raises(ValueError):
         augment.apply_augment(t('a5'), t('b5'), ['mixup'], [1.0], [1.0])
+
+
+def test_edvr_predeblur_hr_in_schema_matches_reference():
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    g = load_golden('edvr_predeblur')
+    for tag, kw in (('pre', dict(predeblur=True, HR_in=False)), ('hr', dict(predeblur=False, HR_in=True)),
+                    ('prehr', dict(predeblur=True, HR_in=True))):
+        net = EDVR(nf=64, nc=3, nframes=3, groups=8, front_RBs=1, back_RBs=1, w_TSA=False, **kw)
+        assert sorted(net.state_dict().keys()) == [str(k) for k in g[tag + '.keys']], tag
