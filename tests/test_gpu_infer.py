@@ -65,3 +65,14 @@ def test_sliding_window_x4_and_flip():
     a, b = run(clip), run.reference_order(clip)
     assert a.shape == (6, 3, 64, 96)
     assert torch.equal(a, b)
+
+
+def test_sliding_window_hipgraph_is_bit_identical():
+    from realvsr_amd.infer import SlidingWindowRunner
+    net = _tiny_net()
+    torch.manual_seed(9)
+    clip = torch.rand(6, 3, 24, 40, device=dev())
+    eager = SlidingWindowRunner(net, 3, padding='reflection', chunk=4)(clip)
+    run = SlidingWindowRunner(net, 3, padding='reflection', chunk=4, use_graph=True)
+    assert torch.equal(run(clip), eager)
+    assert torch.equal(run(clip.flip(0)), SlidingWindowRunner(net, 3, padding='reflection', chunk=4)(clip.flip(0)))  # graph reused

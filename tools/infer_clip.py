@@ -50,8 +50,11 @@ def timed(fn):
 
 ref, ms_ref = timed(lambda: run.reference_order(clip))
 out, ms_reuse = timed(lambda: run(clip))
+run_g = SlidingWindowRunner(net, a.nframes, padding=a.padding, chunk=2, use_graph=True)
+out_g, ms_graph = timed(lambda: run_g(clip))
 bgr = ycbcr_to_bgr_u8(out[0])
 print(json.dumps({'config': 'EDVR nf%d %df %dx%d x4, clip of %d frames, padding %s' % (a.nf, a.nframes, a.height, a.width, a.T, a.padding),
                   'ms_per_frame_window_by_window': round(ms_ref, 2), 'ms_per_frame_feature_reuse': round(ms_reuse, 2),
-                  'speedup': round(ms_ref / ms_reuse, 3), 'bit_identical': bool(torch.equal(ref, out)),
+                  'ms_per_frame_feature_reuse_hipgraph': round(ms_graph, 2), 'speedup': round(ms_ref / ms_reuse, 3),
+                  'bit_identical': bool(torch.equal(ref, out)), 'graph_bit_identical': bool(torch.equal(out_g, out)),
                   'bgr_u8_shape': list(bgr.shape), 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
