@@ -1523,3 +1523,114 @@ int rvsr_launch_conv_wgrad1x1(const ConvWgradParams& p, int gy, int gz, hipStrea
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad1x1 launch: %s", hipGetErrorString(e));
     return RVSR_OK;
 }
+
+// ==========================================================================================
+// Weight gradient of a 3x3 STRIDE-2 convolution (pad 1) on the bf16 matrix cores, direct from global memory like
+// conv_wgrad1x1_kernel:   gW[o][c][dy][dx] = sum_{b, py, px} G[o][py][px] * X[c][2 py + dy - 1][2 px + dx - 1].
+// K = output pixels; lane (row, k-octet) holds 8 consecutive output pixels of one output row.  For X that is a
+// stride-2 walk over input columns 2 px0 + dx - 1 + 2 i: the lane loads the 20 input values of columns
+// 2 px0 - 4 .. 2 px0 + 15 of an input row with five aligned 16-byte loads and picks the three dx variants out of
+// registers (static indices, no shuffles); the three dy variants are three input rows.  One workgroup = 4 waves =
+// a 64(o) x 64(c) block of all 9 taps (9 accumulator tiles per wave) over a slice of the pixels; deterministic
+// partial sums.  Replaces the exact-f32 LDS-staged fallback (2.5 ms/step for the two pyramid convs of config 2).
+template <bool ACT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_s2_kernel(const ConvWgradParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int m = wave & 1, n = wave >> 1;
+    const int C = p.x.a.C;                       // single input (no concat on this path)
+    const int Hin = p.x.a.Hs, Win = p.x.a.Ws;
+    const int Ho = p.Hout, Wo = p.Wout;
+    const int o = blockIdx.y * 64 + m * 32 + lo;   // this lane's G row
+    const int c = blockIdx.z * 64 + n * 32 + lo;   // this lane's X row
+    const bool o_ok = o < p.Co, c_ok = c < C;
+    const int oc = o_ok ? o : 0, cc = c_ok ? c : 0;
+    const int UW = (Wo + 15) / 16;                 // 16-pixel units per output row
+    const long units = (long)p.B * Ho * UW;
+    const long per = (units + p.P - 1) / p.P;
+    long u0 = (long)blockIdx.x * per, u1 = u0 + per;
+    if (u1 > units) u1 = units;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = zero16();
+    float bsum = 0.f;
+    for (long u = u0; u < u1; ++u) {
+        const int b = (int)(u / ((long)Ho * UW));
+        const int rem = (int)(u - (long)b * Ho * UW);
+        const int py = rem / UW, px0 = (rem - py * UW) * 16 + 8 * hi;   // this lane's 8 output pixels: px0 .. px0+7
+        const bool pv = px0 < Wo;                                        // Wo % 8 == 0: all 8 or none
+        // ---- G (and act') : two 16-byte loads
+        const size_t gidx = (((size_t)b * p.Co + oc) * Ho + py) * Wo + (pv ? px0 : 0);
+        const float4 g0 = *reinterpret_cast<const float4*>(p.g.p + gidx), g1 = *reinterpret_cast<const float4*>(p.g.p + gidx + 4);
+        float4 a0, a1;
+        if (ACT) {
+            a0 = *reinterpret_cast<const float4*>(p.g.act + gidx);
+            a1 = *reinterpret_cast<const float4*>(p.g.act + gidx + 4);
+        }
+        // ---- X: three input rows x five 16-byte groups (columns 2 px0 - 4 + 4 j .. +3)
+        float xr[3][20];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * py + dy - 1;
+            const bool rok = pv && c_ok && iy >= 0 && iy < Hin;
+            const float* row = p.x.a.p + (((size_t)b * C + cc) * Hin + (rok ? iy : 0)) * Win;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int col = 2 * px0 - 4 + 4 * j;
+                const bool ok = rok && col >= 0 && col < Win;   // Win % 4 == 0: the group is entirely in or out
+                const float4 q = *reinterpret_cast<const float4*>(row + (ok ? col : 0));
+                xr[dy][4 * j + 0] = ok ? q.x : 0.f; xr[dy][4 * j + 1] = ok ? q.y : 0.f;
+                xr[dy][4 * j + 2] = ok ? q.z : 0.f; xr[dy][4 * j + 3] = ok ? q.w : 0.f;
+            }
+        }
+        float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        if (ACT) {
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] *= av[j] > 0.f ? 1.f : p.g.slope;
+        }
+        const bool gok = pv && o_ok;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gv[j] = gok ? gv[j] : 0.f;
+            bsum += gv[j];
+        }
+        bf16x8 gh, gl;
+        split8(gv, gh, gl);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float xv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[i] = xr[dy][3 + dx + 2 * i];   // column 2 (px0 + i) + dx - 1
+                bf16x8 xh, xl;
+                split8(xv, xh, xl);
+                f32x16& a = acc[dy * 3 + dx];
+                a = mfma_bf16(gh, xh, a);
+                a = mfma_bf16(gh, xl, a);
+                a = mfma_bf16(gl, xh, a);
+            }
+        }
+    }
+    float* part = p.part + (size_t)blockIdx.x * p.Co * C * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = blockIdx.y * 64 + m * 32 + drow(r, hi);
+            if (orow < p.Co && c_ok) part[((size_t)orow * C + c) * 9 + t] = acc[t][r];
+        }
+    }
+    if (p.bpart != nullptr && blockIdx.z == 0 && n == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (hi == 0 && o_ok) p.bpart[(size_t)blockIdx.x * p.Co + o] = bsum;
+    }
+}
+
+int rvsr_launch_conv_wgrad_s2(const ConvWgradParams& p, int gy, int gz, hipStream_t st) {
+    auto k = p.g.act != nullptr ? conv_wgrad_s2_kernel<true> : conv_wgrad_s2_kernel<false>;
+    hipLaunchKernelGGL(k, dim3(p.P, gy, gz), dim3(256), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad_s2 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}

@@ -88,3 +88,4 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
 extern int rvsr_g_gemm_mode;
 int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
 int rvsr_launch_conv_wgrad1x1(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
+int rvsr_launch_conv_wgrad_s2(const ConvWgradParams& p, int gy, int gz, hipStream_t st);

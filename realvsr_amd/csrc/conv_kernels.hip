@@ -370,6 +370,14 @@ static int wgrad_P(int ntiles, int gy, int gz, int ksize) {
     if (P > ntiles) P = ntiles;
     return P;
 }
+// stride-2 bf16x3 kernel: 2 workgroups of 4 waves per CU, pixels cut into 16-pixel units
+static int wgrad_s2_P(int B, int Hout, int Wout, int gy, int gz64) {
+    long units = (long)B * Hout * ((Wout + 15) / 16);
+    int P = 512 / (gy * gz64);
+    if (P < 1) P = 1;
+    if (P > units) P = (int)units;
+    return P;
+}
 static void wgrad_geom(int ksize, int stride, int Co, int Ctot, int& ccw, int& gy, int& gz) {
     ccw = (ksize == 3 && stride == 2) ? 32 : 64;
     gy = (Co + 63) / 64;
@@ -381,7 +389,11 @@ extern "C" size_t rvsr_conv2d_wgrad_workspace_bytes(int C1, int C2, int Co, int 
     int ccw, gy, gz;
     wgrad_geom(ksize, stride, Co, C1 + C2, ccw, gy, gz);
     const int ntiles = B * ((Hout + 3) / 4) * ((Wout + 31) / 32);
-    const size_t P = wgrad_P(ntiles, gy, gz, ksize);
+    size_t P = wgrad_P(ntiles, gy, gz, ksize);
+    if (ksize == 3 && stride == 2) {  // the bf16x3 stride-2 kernel slices the pixels differently
+        const size_t P2 = wgrad_s2_P(B, Hout, Wout, gy, (C1 + C2 + 63) / 64);
+        if (P2 > P) P = P2;
+    }
     return sizeof(float) * P * ((size_t)Co * (C1 + C2) * ksize * ksize + Co);
 }
 
@@ -441,7 +453,12 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
         rc = rvsr_launch_conv_wgrad1x1(p, gy, gz, st);
     else if (ksize == 3 && stride == 1)
         rc = launch_wgrad<3, 1, 64>(p, gy, gz, st);
-    else if (ksize == 3)
+    else if (ksize == 3 && rvsr_g_gemm_mode == 0 && x2 == nullptr && g_mode == 0 && (Wout % 8) == 0 && (Win % 4) == 0 && aligned16) {
+        const int gz64 = (Ctot + 63) / 64;
+        p.P = wgrad_s2_P(B, Hout, Wout, gy, gz64);
+        p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;
+        rc = rvsr_launch_conv_wgrad_s2(p, gy, gz64, st);
+    } else if (ksize == 3)
         rc = launch_wgrad<3, 2, 32>(p, gy, gz, st);
     else
         rc = launch_wgrad<1, 1, 64>(p, gy, gz, st);

@@ -29,6 +29,8 @@ CASES = [
     (32, 32, 16, 1, 1, 'lrelu', False, False, 1, 9, 33),
     (64, 64, 80, 1, 1, 'lrelu', False, False, 2, 10, 36),   # concat 1x1 on the GEMM weight-gradient path (HW % 8 == 0)
     (64, 0, 64, 3, 2, 'relu', False, False, 1, 23, 37),      # odd sizes through the zero-insert data gradient
+    (64, 0, 64, 3, 2, 'lrelu', False, False, 2, 32, 48),     # stride-2 weight gradient on the bf16x3 direct-load kernel
+    (16, 0, 24, 3, 2, 'none', False, False, 1, 18, 32),      # same, odd output height, Co/C not multiples of 32
     (128, 0, 128, 3, 1, 'relu', False, False, 1, 12, 36),
     (64, 0, 64, 3, 1, 'lrelu', True, False, 1, 16, 24),   # act + residual (sAtt_3 pattern)
 ]
