@@ -1,32 +1,41 @@
 #!/usr/bin/env python
 """bench.py -- HR frames/sec (fwd + loss + bwd + optimizer step) of the EDVR hot path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run,
-one rank per GPU over RCCL).  W untimed warm-up steps, then EXACTLY K steps bracketed by
-barrier + torch.cuda.synchronize() on both sides; max over ranks; rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N > 1: one rank per GPU over RCCL; either the driver
+launches the ranks (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*) or, when WORLD_SIZE is unset,
+this script re-executes itself under torch.distributed.run with N ranks (the analogue of codes/train.py:19-26).
+W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides; max over
+ranks; rank 0 prints ONE JSON line.
 
-Workload = BASELINE.json configs[1] ("EDVR-M 64ch, 5-frame 180x320 LR, batch 8, fwd+bwd on
-1xMI355X"): EDVR(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, w_TSA=True), x4 output,
-loss = LapPyrLoss(3,'cb','cb') on Y + GWLoss(w=4) on CbCr (the composition of the reference's
-optimize_parameters, VideoSR_AllPair_model_YCbCr_Split.py:163-191, with the in-tree 'cb' low-frequency term), Adam.  Synthetic data:
-x ~ U[0,1) seed 1234, GT ~ U[0,1) seed 1235, default module init under seed 0 with
-conv_offset_mask.weight ~ N(0, 0.01^2) so the deformable offsets are non-zero.  Weak scaling:
-every rank processes its own B=8 windows; value = N*B*K / time.
+Workload = BASELINE.json configs[1] ("EDVR-M 64ch, 5-frame 180x320 LR, batch 8, fwd+bwd on 1xMI355X"):
+EDVR(nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10, w_TSA=True), x4 output, driven through the package's
+train-step harness realvsr_amd.VideoSR_model.VideoSRModel.optimize_parameters -- the reference's step sequence
+(VideoSR_AllPair_model_YCbCr_Split.py:163-191): zero_grad, netG, 1.0 * LapPyrLoss(3,'ssim','cb') on Y +
+1.0 * GWLoss(w=4) on CbCr (the criteria 'lappyr' / 'gw' of the shipped option files), backward, Adam(0.9, 0.99).
+`--lf-mode cb` swaps the (third-party, parity-unpinned) SSIM low-frequency term for the in-tree Charbonnier one.
+Synthetic data: x ~ U[0,1) seed 1234, GT ~ U[0,1) seed 1235, default module init under seed 0 with
+conv_offset_mask.weight ~ N(0, 0.01^2).  With that init the deformable offsets are ~0.004 px; `--offset-px P`
+rescales the offset rows of every conv_offset_mask so that the mean |offset| of each DCN is P px (trained EDVR: several
+px); the line reports the measured offset statistics either way.  Weak scaling: every rank processes its own B
+windows; value = N*B*K / time.
 
 Extra objects on the line:
-  roofline     -- the DCN forward kernel (dcn_fwd_kernel, the kernel north_star grades): algorithmic
-                  bytes 4*(C+216+Co) per output pixel summed over the timed DCN
-                  launches / their HIP-event durations, vs the 8 TB/s HBM3E peak.
-  cpu_baseline -- the CPU oracle (oracle/edvr_oracle.py, kind "port") on ONE window of the same
-                  workload (B=1), timed on this box's host cores (rank 0, N=1 only).
+  roofline     -- the fused DCN forward kernel (the kernel north_star grades): algorithmic bytes 4*(C+216+Co) per
+                  output pixel summed over the timed DCN launches / their HIP-event durations, vs the
+                  8 TB/s HBM3E peak.  `traffic` is NOT measured in this run: it is the PMC measurement kept under
+                  profiles/ rescaled to this run's launch size (`traffic_source` names the file).
+  cpu_baseline -- the CPU oracle (oracle/edvr_oracle.py, kind "port") on ONE window of the same workload (B=1),
+                  1 warm-up + best-of-3, timed on this box's host cores (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-os.environ.setdefault('OMP_NUM_THREADS', str(min(os.cpu_count() or 1, 32)))  # CPU oracle threads (cpu_baseline)
+os.environ.setdefault('OMP_NUM_THREADS', str(os.cpu_count() or 1))  # CPU oracle threads (cpu_baseline)
 
 import torch
 
@@ -34,18 +43,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_PROFILE = {64: 'profiles/r01_dcn_fwd_pmc.json', 128: 'profiles/r02_dcn_fwd_pmc_nf128.json'}
 
 
-def build_net(nf, nframes, back_RBs, device):
-    from realvsr_amd.archs.EDVR_arch import EDVR
-    torch.manual_seed(0)
-    net = EDVR(nf=nf, nc=3, nframes=nframes, groups=8, front_RBs=5, back_RBs=back_RBs, w_TSA=True)
+def model_opt(args, world):
+    net = dict(which_model_G='EDVR', nf=args.nf, nc=3, nframes=args.nframes, groups=8, front_RBs=5,
+               back_RBs=args.back_rbs, center=None, predeblur=False, HR_in=False, w_TSA=True)
+    return {'model': 'VideoSR_AllPair_YCbCr_Split', 'dist': world > 1, 'gpu_ids': [0], 'is_train': True, 'scale': 4,
+            'augment': None, 'network_G': net, 'path': {'pretrain_model_G': None, 'strict_load': True},
+            'train': {'pixel_criterion_y': 'lappyr', 'pixel_weight_y': 1.0, 'pixel_criterion_c': 'gw',
+                      'pixel_weight_c': 1.0, 'weight_decay_G': 0, 'ft_tsa_only': 0, 'lr_G': 1e-4, 'beta1': 0.9,
+                      'beta2': 0.99}}
+
+
+def init_weights(net, offset_init_std=0.01):
+    """Default module init under seed 0 was done by the caller; give conv_offset_mask non-zero weights (zero-init would
+    make every DCN a plain conv)."""
     gen = torch.Generator().manual_seed(99)
     with torch.no_grad():
         for name, p in net.named_parameters():
             if 'conv_offset_mask.weight' in name:
-                p.copy_(torch.randn(p.shape, generator=gen) * 0.01)
-    return net.to(device)
+                p.copy_((torch.randn(p.shape, generator=gen) * offset_init_std).to(p.device))
+
+
+def dcn_packs(net):
+    from realvsr_amd.archs.dcn import ModulatedDeformConvPack
+    return [(n, m) for n, m in net.named_modules() if isinstance(m, ModulatedDeformConvPack)]
+
+
+def offset_stats(net, x, target_px=None):
+    """One no-grad forward with a pre-hook on every DCN pack: mean / max |offset| of its conv_offset_mask output.
+    With target_px the OFFSET rows (first 2/3 of the output channels; the mask rows are left alone) of each pack's
+    conv_offset_mask are rescaled, in forward order, so that its mean |offset| becomes target_px."""
+    from realvsr_amd import functional as RF
+    stats, hooks = {}, []
+
+    def make(name, pack):
+        def pre(_mod, inputs):
+            feat = inputs[0][1] if pack.extra_offset_mask else inputs[0]
+            n_off = pack.conv_offset_mask.out_channels * 2 // 3
+            with torch.no_grad():
+                off = RF.conv2d(feat, pack.conv_offset_mask)[:, :n_off]
+                mean = off.abs().mean().item()
+                if target_px is not None and mean > 0:
+                    s = target_px / mean
+                    pack.conv_offset_mask.weight[:n_off] *= s
+                    pack.conv_offset_mask.bias[:n_off] *= s
+                    off = off * s
+                stats[name] = (off.abs().mean().item(), off.abs().max().item())
+        return pre
+
+    for name, pack in dcn_packs(net):
+        hooks.append(pack.register_forward_pre_hook(make(name, pack)))
+    with torch.no_grad():
+        net(x)
+    for h in hooks:
+        h.remove()
+    return stats
 
 
 def make_batch(B, N, H, W, device, rank=0):
@@ -62,12 +116,11 @@ class DcnTimer:
 
     def install(self):
         from realvsr_amd import functional as RF
-        L = RF._lib.lib()
-        orig = L.rvsr_dcn_pack_forward
+        orig = RF._lib.lib().rvsr_dcn_pack_forward
         timer = self
 
         def timed(*a):
-            # a: input, weight, bias, om, output, B, C, H, W, Co, stride, pad, dil, dg, act, slope, stream
+            # a: input, weight, bias, om, output, B, C, H, W, Co, stride, pad, dil, dg, act, slope, ws, ws_bytes, stream
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = orig(*a)
@@ -79,7 +132,6 @@ class DcnTimer:
             timer.bytes += 4.0 * (C * H * W + (216 + Co) * Ho * Wo) * B + 4.0 * Co * C * 9
             return rc
 
-        self._orig, self._L = orig, L
         _Proxy.wrap(RF, 'rvsr_dcn_pack_forward', timed)
 
     def uninstall(self):
@@ -88,8 +140,7 @@ class DcnTimer:
 
     def result(self):
         ms = sum(s.elapsed_time(e) for s, e in self.events)
-        n = len(self.events)
-        return n, ms, self.bytes
+        return len(self.events), ms, self.bytes
 
 
 class _Proxy:
@@ -112,33 +163,61 @@ class _Proxy:
         RF._lib._lib = _Proxy._real
 
 
-def cpu_baseline(nf, nframes, back_RBs, H, W):
-    """One window (B=1) of the same workload through the CPU oracle: fwd + loss + bwd."""
+def cpu_baseline(args):
+    """One window (B=1) of the same workload through the CPU oracle: fwd + loss + bwd; BASELINE.md section 2 protocol
+    (1 warm-up, then best of 3).  The warm-up runs with every host core, a second probe with 32 threads (torch's CPU
+    conv path stops scaling well below 256 hardware threads); the faster setting is used for the timed runs."""
     from oracle import edvr_oracle as O
     from realvsr_amd.archs.EDVR_arch import EDVR
+    nf, N, H, W = args.nf, args.nframes, args.height, args.width
     torch.manual_seed(0)
-    net = EDVR(nf=nf, nc=3, nframes=nframes, groups=8, front_RBs=5, back_RBs=back_RBs, w_TSA=True)
-    gen = torch.Generator().manual_seed(99)
-    sd = {}
-    for k, v in net.state_dict().items():
-        v = v.detach().clone()
-        if 'conv_offset_mask.weight' in k:
-            v = torch.randn(v.shape, generator=gen) * 0.01
-        sd[k] = v.requires_grad_(True)
-    # bounded thread count: the conv-heavy torch CPU path stops scaling (and collapses from
-    # oversubscription) well below the 256 hardware threads of the GPU box's host
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    x = torch.rand(1, nframes, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    net = EDVR(nf=nf, nc=3, nframes=N, groups=8, front_RBs=5, back_RBs=args.back_rbs, w_TSA=True)
+    init_weights(net)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x = torch.rand(1, N, 3, H, W, generator=torch.Generator().manual_seed(1234))
     gt = torch.rand(1, 3, 4 * H, 4 * W, generator=torch.Generator().manual_seed(1235))
-    t0 = time.perf_counter()
-    out = O.edvr_forward(sd, x, nframes=nframes, groups=8, front_RBs=5, back_RBs=back_RBs, w_TSA=True)
-    loss = O.lap_pyr_loss(out[:, 0:1], gt[:, 0:1], 3) + O.gw_loss(out[:, 1:3], gt[:, 1:3], 4)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'HR frames/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 window (B=1, %d frames %dx%d LR) fwd+loss+bwd through oracle/edvr_oracle.py '
-                      '(torch %s CPU ops + OpenMP C DCN), %.1f s' % (nframes, H, W, torch.__version__, dt)}
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = O.edvr_forward(sd, x, nframes=N, groups=8, front_RBs=5, back_RBs=args.back_rbs, w_TSA=True)
+        loss = O.lap_pyr_loss(out[:, 0:1], gt[:, 0:1], 3, lf_mode=args.lf_mode) + O.gw_loss(out[:, 1:3], gt[:, 1:3], 4)
+        loss.backward()
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
+    probe = {ncpu: one()}                       # warm-up (also the all-cores probe)
+    if ncpu > 32:
+        torch.set_num_threads(32)
+        probe[32] = one()
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
+    best = min(one() for _ in range(3))
+    cpu_model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), '')
+    except OSError:
+        pass
+    return {'value': round(1.0 / best, 5), 'unit': 'HR frames/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 window (B=1, %d frames %dx%d LR) fwd+loss+bwd through oracle/edvr_oracle.py (torch %s CPU ops + '
+                      'OpenMP C DCN); 1 warm-up + best of 3 = %.2f s; host: %d hardware threads, %s; thread-count probe %s'
+                      % (N, H, W, torch.__version__, best, ncpu, cpu_model,
+                         {k: round(v, 2) for k, v in probe.items()})}
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -152,13 +231,18 @@ def main():
     ap.add_argument('--back-rbs', type=int, default=10)
     ap.add_argument('--height', type=int, default=180)
     ap.add_argument('--width', type=int, default=320)
+    ap.add_argument('--lf-mode', choices=['ssim', 'cb'], default='ssim')
+    ap.add_argument('--offset-px', type=float, default=None,
+                    help='rescale every conv_offset_mask so that the mean |offset| of its DCN is this many pixels')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
@@ -177,26 +261,33 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
 
     from realvsr_amd import loss as L
     from realvsr_amd import _lib as rlib
-    from realvsr_amd.dist import BucketedGradAllReduce
+    from realvsr_amd.VideoSR_model import create_model
     gemm_mode = rlib.get_gemm_mode()
     B, N, H, W = args.batch, args.nframes, args.height, args.width
-    net = build_net(args.nf, N, args.back_rbs, device)
+    torch.manual_seed(0 if rank == 0 else 12345 + rank)   # ranks > 0 start from DIFFERENT weights on purpose:
+    model = create_model(model_opt(args, world))           # the model broadcasts rank 0's (checked below)
+    if rank == 0:
+        init_weights(model.netG)
+    if world > 1:
+        from realvsr_amd.dist import broadcast_parameters
+        broadcast_parameters(model.netG)
+        probe = model.optimizer_G.buffers.param.double().sum()
+        lo, hi = probe.clone(), probe.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert lo.item() == hi.item(), 'ranks do not hold identical parameters after the broadcast'
+    if args.lf_mode == 'cb':
+        model.cri_pix_y = L.LapPyrLoss(3, 'cb', 'cb', 'mean')
     x, gt = make_batch(B, N, H, W, device, rank)
-    crit_y, crit_c = L.LapPyrLoss(3, 'cb', 'cb', 'mean'), L.GWLoss(w=4)
-    reducer = BucketedGradAllReduce(net.parameters(), bucket_mb=4.0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.99))
-
-    def step():
-        reducer.zero_grad()
-        out = net(x)
-        loss = crit_y(out[:, 0:1], gt[:, 0:1]) + crit_c(out[:, 1:3], gt[:, 1:3])
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        return loss
+    if args.offset_px is not None and rank == 0:
+        offset_stats(model.netG, x, args.offset_px)
+    if args.offset_px is not None and world > 1:
+        broadcast_parameters(model.netG)
+    model.feed_data({'LQs': x, 'GT': gt})
 
     def fence():
         torch.cuda.synchronize()
@@ -204,36 +295,42 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        model.optimize_parameters(i + 1, log=False)
+    off = offset_stats(model.netG, x) if rank == 0 else {}
     timer = DcnTimer()
     timer.install()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for i in range(args.steps):
+        model.optimize_parameters(args.warmup + i + 1, log=False)
     fence()
     dt = time.perf_counter() - t0
     timer.uninstall()
+    loss = model.loss_terms['l_pix']
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     nl, kms, kbytes = timer.result()
-    # HBM traffic of the DCN forward kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 runs,
-    # profiles/r01_dcn_fwd_pmc.json): measured bytes per output pixel x the pixels an average timed launch covers
-    traffic = None
+    # HBM traffic of the DCN forward kernel: NOT measured here.  PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
+    # runs) are kept under profiles/; their bytes per output pixel are rescaled to the pixels an average timed launch covers.
+    traffic, traffic_source = None, None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_dcn_fwd_pmc.json')) as f:
+        with open(os.path.join(ROOT, PMC_PROFILE[args.nf])) as f:
             pmc = json.load(f)
-        if args.nf == 64 and nl > 0:
+        if nl > 0:
             traffic = round(pmc['hbm_bytes_per_pixel'] * (kbytes / nl) / pmc['algorithmic_bytes_per_pixel'])
+            traffic_source = '%s (offline PMC pass at offset std %s px, rescaled to this launch size; not measured in this run)' \
+                % (PMC_PROFILE[args.nf], pmc['shape'].get('offset_std_px'))
     except (OSError, KeyError, ValueError):
         pass
 
     if rank == 0:
+        l1 = off.get('pcd_align.L1_dcnpack', (None, None))
+        lf = "LapPyr(ssim,cb)" if args.lf_mode == 'ssim' else "LapPyr(cb,cb)"
         line = {
-            'metric': 'HR frames/sec (fwd+bwd) on 5-frame 180x320 LR windows',
+            'metric': 'HR frames/sec (fwd+bwd) on %d-frame %dx%d LR windows' % (N, H, W),
             'value': round(world * B * args.steps / dt, 3),
             'unit': 'HR frames/s',
             'n_gpus': world,
@@ -243,24 +340,31 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',  # tensors, accumulation and all non-GEMM math are f32; see config.gemm for the GEMM operands
+            # tensors, accumulation and all non-GEMM math are f32; the GEMM operands are config.gemm
+            'dtype': 'f32 (bf16x3 GEMM)' if gemm_mode == 'bf16x3' else 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'EDVR-M nf%d, %d-frame %dx%d LR windows, batch %d per GPU, x4 output, '
-                                   'fwd + LapPyr(cb,cb) on Y + GWLoss on CbCr + bwd + Adam step'
-                                   % (args.nf, N, H, W, B),
+            'config': {'workload': 'EDVR%s nf%d, %d-frame %dx%d LR windows, batch %d per GPU, x4 output, VideoSRModel.'
+                                   'optimize_parameters: fwd + %s on Y + GWLoss on CbCr + bwd + Adam step'
+                                   % ('-M' if args.nf == 64 else '', args.nf, N, H, W, B, lf),
                        'per_gpu_batch': B, 'global_batch': world * B, 'parallelism': 'sequence-dp%d' % world,
                        'gemm': gemm_mode + (' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)'
                                             if gemm_mode == 'bf16x3' else ' (v_mfma_f32_32x32x2_f32, exact f32)'),
+                       'lf_term': 'ssim (restated IQA_pytorch.SSIM, parity unpinned)' if args.lf_mode == 'ssim' else 'cb',
+                       'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 4),
+                       'offset_abs_max_px': None if l1[1] is None else round(l1[1], 3),
+                       'offset_abs_mean_px_per_dcn': {k.split('.')[-1]: round(v[0], 4) for k, v in off.items()},
+                       'offset_px_requested': args.offset_px,
                        'loss_last_step': round(float(loss.item()), 6)},
             'roofline': {'kernel': 'dcn_fwd2_kernel (+ its weight pre-pack), fused DCN forward', 'bound': 'hbm',
                          'achieved': round(kbytes / (kms * 1e-3) / 1e9, 2) if kms > 0 else None,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
-                         'traffic': traffic, 'launches': nl, 'avg_launch_ms': round(kms / max(nl, 1), 4),
+                         'traffic': traffic, 'traffic_source': traffic_source, 'launches': nl,
+                         'avg_launch_ms': round(kms / max(nl, 1), 4),
                          'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.nf, N, args.back_rbs, H, W)
+            line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

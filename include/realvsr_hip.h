@@ -212,6 +212,59 @@ int rvsr_gwloss_backward(const float* fa, const float* fbx, const float* fby, co
  * clip, *255, round, uint8), same arithmetic order and precisions: bit-exact. */
 int rvsr_ycbcr_to_bgr_u8(const float* ycc, unsigned char* bgr, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 6. The rest of the reference's pixel criteria (codes/models/loss.py) and pyramid helpers
+ * --------------------------------------------------------------------------------------------- */
+
+/* Bytes of the partial-sum workspace the reductions below need. */
+size_t rvsr_reduce_workspace_bytes(void);
+
+/* out[0] = scale * sum f(x - y) over n elements; mode 0: |d| (nn.L1Loss, loss.py:167-168), 1: d^2 (nn.MSELoss, :169-170),
+ * 2: Huber with delta = param (HuberLoss, loss.py:26-40), 3: sqrt(d^2 + param) (CharbonnierLoss, loss.py:10-23).
+ * backward: gx = gscalar[0] * scale * f'(x - y)  (grad w.r.t. y is -gx); gscalar is a device pointer. */
+int rvsr_pixel_loss_forward(const float* x, const float* y, size_t n, int mode, float param, double scale, float* out,
+                            void* workspace, void* stream);
+int rvsr_pixel_loss_backward(const float* x, const float* y, const float* gscalar, int mode, float param, float scale,
+                             float* gx, size_t n, void* stream);
+
+/* SSIM loss as LapPyrLoss(lf_mode='ssim') uses it (loss.py:203,209,222 -> IQA_pytorch.SSIM(channels=1)(x, y, as_loss=True);
+ * third-party, un-vendored: algorithm restated in oracle/ssim_oracle.py, parity unpinned): 11x11 Gaussian window sigma 1.5,
+ * 'valid' correlation, C1 = 0.01^2, C2 = 0.03^2, contrast-structure map clamped at 0, out[0] = 1 - scale * sum(ssim_map)
+ * with scale = 1 / (planes (H-10) (W-10)).  ga/gb/gc (NULL together, or planes x (H-10) x (W-10) each) receive
+ * dS/dmu_x, dS/dE[xx], dS/dE[xy] for the backward: gx = -gscalar[0] * scale * window-adjoint(ga + 2 x gb + y gc). */
+int rvsr_ssim_forward(const float* x, const float* y, size_t planes, int H, int W, double scale, float* out, float* ga,
+                      float* gb, float* gc, void* workspace, void* stream);
+int rvsr_ssim_backward(const float* x, const float* y, const float* ga, const float* gb, const float* gc,
+                       const float* gscalar, float scale, float* gx, size_t planes, int H, int W, void* stream);
+
+/* conv_gauss(img, gain * gauss_kernel) (utils/util.py:503-506): reflect-pad 2 + depthwise 5x5 binomial /256, same size. */
+int rvsr_conv_gauss_forward(const float* in, float* out, size_t planes, int H, int W, float gain, void* stream);
+int rvsr_conv_gauss_backward(const float* gout, float* gin, size_t planes, int H, int W, float gain, void* stream);
+/* upsample(x) (utils/util.py:513-516): zero-insert to 2H x 2W, conv_gauss with 4 * kernel.  in planes x H x W. */
+int rvsr_pyr_upsample_forward(const float* in, float* out, size_t planes, int H, int W, void* stream);
+int rvsr_pyr_upsample_backward(const float* gout, float* gin, size_t planes, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 7. The two steps either side of netG in optimize_parameters
+ * --------------------------------------------------------------------------------------------- */
+
+/* One torch.optim.Adam update (VideoSR_AllPair_model_YCbCr_Split.py:122-124,187) of n contiguous f32 parameters, in place:
+ *   g' = grad + weight_decay * param; exp_avg += (g' - exp_avg)(1 - beta1); exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g'^2;
+ *   param -= step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
+ * with step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller. 16-byte aligned buffers. */
+int rvsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float step_size, float beta1,
+                   float beta2, float eps, float weight_decay, float bias_correction2_sqrt, void* stream);
+
+/* CutBlur / rgb-permute / blend of a clip pair (data/augments_video_allpair.py:38-88) in one pass over `frames` x 3 x H x W:
+ *   a = im1[f, perm[c]], b = im2[f, perm[c]];  out1 = a;  out2 = b            (box_mode 0)
+ *                                              out2 = inside box ? a : b      (box_mode 1: im1's box pasted into im2)
+ *                                              out2 = inside box ? b : a      (box_mode 2: im2's box pasted into a copy of im1)
+ *   colour != NULL (frames x 3): out = v * out + (1 - v) * colour[f, c]        (blend)
+ * The random decisions (which augmentation, box, permutation, v) are drawn by the caller in the reference's host-RNG order. */
+int rvsr_augment_clips(const float* im1, const float* im2, float* out1, float* out2, const float* colour, size_t frames, int H,
+                       int W, int perm0, int perm1, int perm2, int box_mode, int y0, int y1, int x0, int x1, float v,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

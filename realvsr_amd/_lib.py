@@ -51,6 +51,17 @@ SIGNATURES = {
     'rvsr_gwloss_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     'rvsr_gwloss_backward': (c_int, [c_fp, c_fp, c_fp, c_fp, c_float, c_fp, c_size, c_int, c_int, c_fp]),
     'rvsr_ycbcr_to_bgr_u8': (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
+    'rvsr_reduce_workspace_bytes': (c_size, []),
+    'rvsr_pixel_loss_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_float, c_double, c_fp, c_fp, c_fp]),
+    'rvsr_pixel_loss_backward': (c_int, [c_fp, c_fp, c_fp, c_int, c_float, c_float, c_fp, c_size, c_fp]),
+    'rvsr_ssim_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    'rvsr_ssim_backward': (c_int, [c_fp] * 6 + [c_float, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_conv_gauss_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_fp]),
+    'rvsr_conv_gauss_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_fp]),
+    'rvsr_pyr_upsample_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_pyr_upsample_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
+    'rvsr_adam_step': (c_int, [c_fp] * 4 + [c_size] + [c_float] * 6 + [c_fp]),
+    'rvsr_augment_clips': (c_int, [c_fp] * 5 + [c_size] + [c_int] * 10 + [c_float, c_fp]),
 }
 
 

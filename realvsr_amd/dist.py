@@ -7,42 +7,60 @@ N-frame windows are independent, so the only exchange on the hot path is one gra
 all-reduce per step (13.2 MB for EDVR-M).
 
 Design for xGMI (point-to-point links, ring all-reduce is per-link bound): all gradients live in
-ONE flat f32 buffer (p.grad are views), cut into a few large buckets in reverse registration
-order (~ the order backward produces them); a bucket's all-reduce is issued asynchronously the
-moment its last gradient has been accumulated, so the big early buckets (reconstruction trunk,
-fusion) travel while the PCD/feature-extraction backward is still running.
+ONE flat f32 buffer (p.grad are views; the same buffer ``optim.FlatAdam`` consumes), cut into a few
+large buckets in reverse registration order (~ the order backward produces them); a bucket's
+all-reduce is issued asynchronously the moment its last gradient has been accumulated, so the big
+early buckets (reconstruction trunk, fusion) travel while the PCD/feature-extraction backward is
+still running.  Collectives are always issued in ascending bucket order on every rank (a bucket that
+completes early waits for its predecessors), so ranks whose parameters receive gradients in a
+different order -- or not at all -- still pair up the same collectives.
 """
 import torch
 import torch.distributed as dist
 
+from .optim import FlatBuffers
+
+
+def broadcast_parameters(module_or_tensors, src=0, process_group=None):
+    """Make every rank start from rank `src`'s parameters and buffers (DistributedDataParallel does this in its
+    constructor, VideoSR_AllPair_model_YCbCr_Split.py:33-34)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    if isinstance(module_or_tensors, torch.nn.Module):
+        tensors = [p.data for p in module_or_tensors.parameters()] + [b.data for b in module_or_tensors.buffers()]
+    else:
+        tensors = [t.data if isinstance(t, torch.nn.Parameter) else t for t in module_or_tensors]
+    for t in tensors:
+        dist.broadcast(t, src=src, group=process_group)
+
 
 class BucketedGradAllReduce:
-    def __init__(self, params, bucket_mb=4.0, process_group=None):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, bucket_mb=4.0, process_group=None, buffers=None, broadcast=True):
+        """params: iterable of parameters (ignored when `buffers`, a FlatBuffers that already holds them, is given)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        # reverse order: parameters used last in forward get their gradients first
-        order = list(reversed(self.params))
-        self.buckets = []       # (start, end) ranges in self.flat
+        self.buffers = buffers if buffers is not None else FlatBuffers([list(params)])
+        self.params = list(self.buffers.order)
+        self.flat = self.buffers.grad
+        if broadcast and self.world > 1:
+            dist.broadcast(self.buffers.param, src=0, group=process_group)   # one collective for all parameters
+        self.buckets = []       # (start, end) ranges in self.flat, ascending
         self._bucket_of = {}
-        off, start, cap = 0, 0, int(bucket_mb * (1 << 20) / 4)
-        for p in order:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+        cap = int(bucket_mb * (1 << 20) / 4)
+        start = 0
+        for i, p in enumerate(self.params):
             self._bucket_of[p] = len(self.buckets)
-            off += n
-            if off - start >= cap:
-                self.buckets.append((start, off))
-                start = off
-        if off > start:
-            self.buckets.append((start, off))
+            end = self.buffers.offset[self.params[i + 1]] if i + 1 < len(self.params) else self.buffers.numel
+            if end - start >= cap:
+                self.buckets.append((start, end))
+                start = end
+        if self.buffers.numel > start:
+            self.buckets.append((start, self.buffers.numel))
         self._need = [0] * len(self.buckets)
-        for p in order:
+        for p in self.params:
             self._need[self._bucket_of[p]] += 1
         self._pending = list(self._need)
+        self._next = 0          # next bucket to issue (strictly ascending on every rank)
         self._works = []
         if self.world > 1:
             for p in self.params:
@@ -51,23 +69,27 @@ class BucketedGradAllReduce:
     def zero_grad(self):
         self.flat.zero_()
         self._pending = list(self._need)
+        self._next = 0
         self._works = []
 
-    def _hook(self, p):
-        b = self._bucket_of[p]
-        self._pending[b] -= 1
-        if self._pending[b] == 0:
-            s, e = self.buckets[b]
+    def _issue_ready(self):
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            s, e = self.buckets[self._next]
             self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._next += 1
+
+    def _hook(self, p):
+        self._pending[self._bucket_of[p]] -= 1
+        self._issue_ready()
 
     def finish(self):
         """Wait for the in-flight buckets and turn the sums into means. Call before optimizer.step()."""
         if self.world == 1:
             return
-        for b, left in enumerate(self._pending):  # parameters that received no gradient this step
-            if left > 0:
-                s, e = self.buckets[b]
-                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.buffers.check_bound()
+        for b in range(self._next, len(self.buckets)):   # buckets holding parameters that got no gradient this step
+            self._pending[b] = 0
+        self._issue_ready()
         for w in self._works:
             w.wait()
         self.flat.mul_(1.0 / self.world)

@@ -6,6 +6,7 @@ operator; CPU tensors are refused (NotImplementedError, like the reference's ope
 codes/models/archs/dcn/deform_conv.py:109-110,124-125).
 """
 import ctypes
+import functools
 
 import torch
 from torch.autograd import Function
@@ -25,12 +26,19 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise NotImplementedError('realvsr_amd operators run on MI355X (HIP) tensors only; got a %s tensor'
                                       % t.device.type)
-        if t is not None and t.dtype != torch.float32:
+        if t.dtype != torch.float32:
             raise TypeError('realvsr_amd operators are float32 (like the reference training path); got %s' % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError('realvsr_amd operators need all operands on one device; got %s and %s' % (dev, t.device))
 
 
 def _c(t):
@@ -554,3 +562,210 @@ class _GWLoss(Function):
 def gw_loss(x1, x2, w=4, reduction='mean'):
     """Gradient-weighted loss (codes/models/loss.py:54-80), one fused pass."""
     return _GWLoss.apply(x1, x2, float(w), reduction == 'mean')
+
+
+class _PixelLoss(Function):
+    """scale * sum f(x - y), f = |d| / d^2 / Huber / Charbonnier (rvsr_pixel_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mode, param, mean):
+        _need_cuda(x, y)
+        if x.shape != y.shape:
+            raise RuntimeError('pixel loss: shapes %s and %s differ' % (tuple(x.shape), tuple(y.shape)))
+        x, y = x.contiguous(), y.contiguous()
+        n = x.numel()
+        out = x.new_empty(())
+        L = _lib.lib()
+        ws = _workspace(L.rvsr_reduce_workspace_bytes(), x.device)
+        scale = 1.0 / n if mean else 1.0
+        _lib.check(L.rvsr_pixel_loss_forward(_p(x), _p(y), n, mode, param, scale, _p(out), _p(ws), _stream()),
+                   'pixel_loss_forward')
+        ctx.cfg = (mode, param, scale)
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        mode, param, scale = ctx.cfg
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().rvsr_pixel_loss_backward(_p(x), _p(y), _p(g), mode, param, scale, _p(gx), x.numel(),
+                                                       _stream()), 'pixel_loss_backward')
+        return gx, (-gx if ctx.needs_input_grad[1] else None), None, None, None
+
+
+PIX_L1, PIX_L2, PIX_HUBER, PIX_CHARBONNIER = 0, 1, 2, 3
+
+
+def pixel_loss(x, y, mode, param=0.0, reduction='mean'):
+    """nn.L1Loss / nn.MSELoss / HuberLoss(delta=param) / CharbonnierLoss(eps=param) as one reduction kernel."""
+    return _PixelLoss.apply(x, y, int(mode), float(param), reduction == 'mean')
+
+
+class _SSIMLoss(Function):
+    """1 - mean(ssim_map(x, y)) with the 11x11 sigma-1.5 window (IQA_pytorch.SSIM(...)(x, y, as_loss=True))."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        _need_cuda(x, y)
+        if x.shape != y.shape or x.dim() != 4:
+            raise RuntimeError('ssim: expected two equal (B, C, H, W) tensors, got %s and %s' % (tuple(x.shape), tuple(y.shape)))
+        x, y = x.contiguous(), y.contiguous()
+        B, C, H, W = x.shape
+        out = x.new_empty(())
+        L = _lib.lib()
+        ws = _workspace(L.rvsr_reduce_workspace_bytes(), x.device)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        maps = x.new_empty(3, B * C, H - 10, W - 10) if need and H > 10 and W > 10 else None
+        scale = 1.0 / max(B * C * (H - 10) * (W - 10), 1)
+        _lib.check(L.rvsr_ssim_forward(_p(x), _p(y), B * C, H, W, scale, _p(out),
+                                       _p(maps[0]) if maps is not None else None,
+                                       _p(maps[1]) if maps is not None else None,
+                                       _p(maps[2]) if maps is not None else None, _p(ws), _stream()), 'ssim_forward')
+        ctx.cfg = (scale, B * C, H, W)
+        ctx.save_for_backward(x, y, maps)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y, maps = ctx.saved_tensors
+        scale, planes, H, W = ctx.cfg
+        g = g.contiguous()
+        L = _lib.lib()
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(L.rvsr_ssim_backward(_p(x), _p(y), _p(maps[0]), _p(maps[1]), _p(maps[2]), _p(g), scale, _p(gx),
+                                            planes, H, W, _stream()), 'ssim_backward')
+        if ctx.needs_input_grad[1]:
+            # SSIM is symmetric: the derivative maps w.r.t. the second image are those of ssim(y, x)
+            tmp = x.new_empty(())
+            m2 = torch.empty_like(maps)
+            ws = _workspace(L.rvsr_reduce_workspace_bytes(), x.device)
+            _lib.check(L.rvsr_ssim_forward(_p(y), _p(x), planes, H, W, scale, _p(tmp), _p(m2[0]), _p(m2[1]), _p(m2[2]),
+                                           _p(ws), _stream()), 'ssim_forward (swapped)')
+            gy = torch.empty_like(y)
+            _lib.check(L.rvsr_ssim_backward(_p(y), _p(x), _p(m2[0]), _p(m2[1]), _p(m2[2]), _p(g), scale, _p(gy), planes,
+                                            H, W, _stream()), 'ssim_backward (swapped)')
+        return gx, gy
+
+
+def ssim_loss(x, y):
+    return _SSIMLoss.apply(x, y)
+
+
+class _ConvGauss(Function):
+    @staticmethod
+    def forward(ctx, x, gain):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().rvsr_conv_gauss_forward(_p(x), _p(out), B * C, H, W, gain, _stream()), 'conv_gauss_forward')
+        ctx.cfg = (B * C, H, W, gain)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        planes, H, W, gain = ctx.cfg
+        gout = gout.contiguous()
+        gin = torch.empty_like(gout)
+        _lib.check(_lib.lib().rvsr_conv_gauss_backward(_p(gout), _p(gin), planes, H, W, gain, _stream()),
+                   'conv_gauss_backward')
+        return gin, None
+
+
+def conv_gauss(x, gain=1.0):
+    """conv_gauss(x, gain * gauss_kernel()) (utils/util.py:503-506)"""
+    return _ConvGauss.apply(x, float(gain))
+
+
+class _PyrUpsample(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = x.new_empty(B, C, 2 * H, 2 * W)
+        _lib.check(_lib.lib().rvsr_pyr_upsample_forward(_p(x), _p(out), B * C, H, W, _stream()), 'pyr_upsample_forward')
+        ctx.cfg = (B, C, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        B, C, H, W = ctx.cfg
+        gout = gout.contiguous()
+        gin = gout.new_empty(B, C, H, W)
+        _lib.check(_lib.lib().rvsr_pyr_upsample_backward(_p(gout), _p(gin), B * C, H, W, _stream()),
+                   'pyr_upsample_backward')
+        return gin
+
+
+def pyr_upsample(x):
+    """upsample(x) of the pyramid helpers (utils/util.py:513-516)"""
+    return _PyrUpsample.apply(x)
+
+
+# ------------------------------------------------------------------------------------------ optimizer / augmentation
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step_size, beta1, beta2, eps, weight_decay, bias_correction2_sqrt):
+    """In-place Adam update of one flat f32 buffer (rvsr_adam_step); no autograd."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    n = param.numel()
+    for t in (grad, exp_avg, exp_avg_sq):
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError('adam_step_: buffers must be contiguous and of equal length')
+    with torch.cuda.device(param.device):
+        _lib.check(_lib.lib().rvsr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, step_size, beta1, beta2,
+                                             eps, weight_decay, bias_correction2_sqrt, _stream()), 'adam_step')
+
+
+def augment_clips(im1, im2, perm=(0, 1, 2), box_mode=0, box=(0, 0, 0, 0), v=1.0, colour=None):
+    """One pass over a clip pair [..., 3, H, W] (rvsr_augment_clips): channel permutation, CutBlur box paste
+    (box = (y0, y1, x0, x1)), blend with a per-frame colour.  Returns two new tensors; no autograd (data path)."""
+    _need_cuda(im1, im2, colour)
+    if im1.shape != im2.shape or im1.dim() < 3 or im1.shape[-3] != 3:
+        raise ValueError('augment_clips: expected two equal [..., 3, H, W] clips, got %s and %s'
+                         % (tuple(im1.shape), tuple(im2.shape)))
+    im1, im2 = im1.contiguous(), im2.contiguous()
+    H, W = im1.shape[-2:]
+    frames = im1.numel() // (3 * H * W)
+    if colour is not None:
+        colour = colour.contiguous()
+        if colour.numel() != frames * 3:
+            raise ValueError('augment_clips: colour must hold one value per (frame, channel)')
+    out1, out2 = torch.empty_like(im1), torch.empty_like(im2)
+    with torch.cuda.device(im1.device):
+        _lib.check(_lib.lib().rvsr_augment_clips(_p(im1), _p(im2), _p(out1), _p(out2), _p(colour), frames, H, W,
+                                                 int(perm[0]), int(perm[1]), int(perm[2]), int(box_mode), int(box[0]),
+                                                 int(box[1]), int(box[2]), int(box[3]), float(v), _stream()),
+                   'augment_clips')
+    return out1, out2
+
+
+# ------------------------------------------------------------------------------------------ device guard
+def _guarded(fn):
+    """Run an operator on the device of its tensors: HIP launches go to the CURRENT device, and `_stream()` /
+    `_workspace()` are the current device's, so a module living on cuda:1 while cuda:0 is current (DataParallel
+    replicas, VideoSR_AllPair_model_YCbCr_Split.py:36; the reference's extension does the same with
+    at::DeviceGuard, deform_conv_cuda.cpp:499,581) must switch first."""
+    @functools.wraps(fn)
+    def wrapper(ctx, *args):
+        for a in args:
+            if torch.is_tensor(a) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(ctx, *args)
+                break
+        return fn(ctx, *args)
+    return wrapper
+
+
+for _cls in list(globals().values()):
+    if isinstance(_cls, type) and issubclass(_cls, Function) and _cls is not Function:
+        _cls.forward = staticmethod(_guarded(_cls.forward))
+        _cls.backward = staticmethod(_guarded(_cls.backward))

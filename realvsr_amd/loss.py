@@ -3,7 +3,10 @@
 
 ``lf_mode='ssim'`` / ``hf_mode='ssim'`` call the third-party ``IQA_pytorch.SSIM`` in the
 reference (loss.py:7,203,209) -- an unpinned pip dependency that is not vendored and is absent
-here, so that mode is not implemented (parity would be unpinned); the in-tree 'cb' mode is."""
+here.  ``SSIM`` below is this build's implementation of that package's published algorithm (one
+fused HIP kernel each way); it is checked against the restatement in oracle/ssim_oracle.py, but
+there is no copy of the package to pin either against: parity of the 'ssim' mode is UNPINNED.
+Every other mode is pinned by fixtures generated from the reference's own loss.py."""
 import torch
 import torch.nn as nn
 
@@ -21,6 +24,57 @@ class CharbonnierLoss(nn.Module):
 
     def forward(self, x, y):
         return RF.charbonnier(x, y, self.eps, 'mean' if self.reduction == 'mean' else 'sum')
+
+
+class HuberLoss(nn.Module):
+    """Huber Loss (codes/models/loss.py:26-40): 0.5 q^2 + delta (|d| - q), q = min(|d|, delta)."""
+
+    def __init__(self, delta=1e-2, reduction='mean'):
+        super(HuberLoss, self).__init__()
+        self.delta = delta
+        self.reduction = reduction
+
+    def forward(self, x, y):
+        return RF.pixel_loss(x, y, RF.PIX_HUBER, self.delta, 'mean' if self.reduction == 'mean' else 'sum')
+
+
+class _ElementwiseLoss(nn.Module):
+    """nn.L1Loss / nn.MSELoss stand-ins (loss.py:167-170) on the HIP reduction kernel."""
+    mode = RF.PIX_L1
+
+    def __init__(self, reduction='mean'):
+        super(_ElementwiseLoss, self).__init__()
+        if reduction not in ('mean', 'sum'):
+            raise ValueError("reduction must be 'mean' or 'sum' (got %r)" % (reduction,))
+        self.reduction = reduction
+
+    def forward(self, x, y):
+        return RF.pixel_loss(x, y, self.mode, 0.0, self.reduction)
+
+
+class L1Loss(_ElementwiseLoss):
+    mode = RF.PIX_L1
+
+
+class MSELoss(_ElementwiseLoss):
+    mode = RF.PIX_L2
+
+
+class SSIM(nn.Module):
+    """``IQA_pytorch.SSIM(channels)(X, Y, as_loss=True)`` -> 1 - mean SSIM (11x11 Gaussian window, sigma 1.5, valid
+    correlation, C1 = 0.01^2, C2 = 0.03^2, contrast-structure map clamped at 0); ``as_loss=False`` returns the
+    per-image score without a graph.  Third-party algorithm restated from its publication: parity unpinned."""
+
+    def __init__(self, channels=3):
+        super(SSIM, self).__init__()
+        self.channels = channels
+
+    def forward(self, X, Y, as_loss=True):
+        assert X.shape == Y.shape
+        if as_loss:
+            return RF.ssim_loss(X, Y)
+        with torch.no_grad():
+            return torch.stack([1.0 - RF.ssim_loss(X[i:i + 1], Y[i:i + 1]) for i in range(X.shape[0])])
 
 
 class GWLoss(nn.Module):
@@ -46,9 +100,11 @@ class PyramidLoss(nn.Module):
         self.loss_mode = loss_mode
         assert self.pyr_mode == 'gau' or self.pyr_mode == 'lap'
         if self.loss_mode == 'l1':
-            self.loss = nn.L1Loss(reduction=reduction)
+            self.loss = L1Loss(reduction=reduction)
         elif self.loss_mode == 'l2':
-            self.loss = nn.MSELoss(reduction=reduction)
+            self.loss = MSELoss(reduction=reduction)
+        elif self.loss_mode == 'hb':
+            self.loss = HuberLoss(reduction=reduction)
         elif self.loss_mode == 'cb':
             self.loss = CharbonnierLoss(reduction=reduction)
         else:
@@ -72,14 +128,18 @@ class LapPyrLoss(nn.Module):
         self.num_levels = num_levels
         self.lf_mode = lf_mode
         self.hf_mode = hf_mode
-        for mode in (lf_mode, hf_mode):
-            if mode == 'ssim':
-                raise NotImplementedError("'ssim' needs the un-vendored IQA_pytorch package (parity unpinned); "
-                                          "use lf_mode='cb'")
-            if mode != 'cb':
-                raise ValueError()
-        self.lf_loss = CharbonnierLoss(reduction=reduction)
-        self.hf_loss = CharbonnierLoss(reduction=reduction)
+        if lf_mode == 'ssim':
+            self.lf_loss = SSIM(channels=1)
+        elif lf_mode == 'cb':
+            self.lf_loss = CharbonnierLoss(reduction=reduction)
+        else:
+            raise ValueError()
+        if hf_mode == 'ssim':
+            self.hf_loss = SSIM(channels=1)
+        elif hf_mode == 'cb':
+            self.hf_loss = CharbonnierLoss(reduction=reduction)
+        else:
+            raise ValueError()
 
     def forward(self, x, y):
         pyr_x = util.laplacian_pyramid(img=x, max_levels=self.num_levels)

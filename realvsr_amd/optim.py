@@ -1,0 +1,136 @@
+"""Adam on flat buffers: the optimizer step of the reference's training loop
+(codes/models/VideoSR_AllPair_model_YCbCr_Split.py:122-124 ``torch.optim.Adam(optim_params, lr, weight_decay, betas)``,
+``.step()`` at :187) as ONE HIP kernel launch per parameter group.
+
+MI355X-first layout: every parameter of the network is a view into one contiguous f32 buffer, every gradient a view
+into a second one laid out identically (the buffer ``realvsr_amd.dist.BucketedGradAllReduce`` all-reduces in
+buckets), and the two Adam moments are two more.  The update is then a single streaming pass over 4 x 13 MB
+(EDVR-M) instead of torch's multi-tensor chain over 144 tensors; ``zero_grad`` is one memset and can never detach a
+gradient from the reduced buffer (torch's ``set_to_none`` default would).
+
+Arithmetic = torch's single-tensor Adam (amsgrad=False), op for op (rvsr_adam_step in csrc/train_kernels.hip);
+``param_groups`` / ``state`` keep torch's schema, so LR schedulers that edit ``param_groups[i]['lr']``
+(base_model.py:36-60) and ``state_dict()`` work unchanged.
+"""
+import math
+
+import torch
+
+from . import functional as RF
+
+_ALIGN = 64  # elements: every parameter starts on a 256-byte boundary of the flat buffers
+
+
+class FlatBuffers:
+    """Re-homes parameters (and their gradients) into contiguous buffers, group by group.
+
+    Within a group the parameters are laid out in REVERSE registration order -- roughly the order backward produces
+    their gradients -- so that the bucketed all-reduce can send the first buckets while backward is still running."""
+
+    def __init__(self, groups):
+        groups = [[p for p in g if p.requires_grad] for g in groups]
+        flat = [p for g in groups for p in g]
+        if not flat:
+            raise ValueError('FlatBuffers: no trainable parameters')
+        ref = flat[0]
+        for p in flat:
+            if p.dtype != torch.float32 or p.device != ref.device:
+                raise ValueError('FlatBuffers: parameters must be float32 on one device')
+        self.order, self.offset, self.group_range = [], {}, []
+        off = 0
+        for g in groups:
+            start = off
+            for p in reversed(g):
+                self.order.append(p)
+                self.offset[p] = off
+                off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            self.group_range.append((start, off))
+        self.numel = off
+        self.param = torch.zeros(off, dtype=torch.float32, device=ref.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=ref.device)
+        with torch.no_grad():
+            for p in self.order:
+                o, n = self.offset[p], p.numel()
+                view = self.param[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def grad_view(self, p):
+        o = self.offset[p]
+        return self.grad[o:o + p.numel()].view(p.shape)
+
+    def check_bound(self):
+        """Raise if something re-bound a parameter or its gradient away from the flat buffers (net.to(), zero_grad(
+        set_to_none=True), p.grad = None, ...): the flat update would then silently work on stale memory."""
+        base_p, base_g = self.param.data_ptr(), self.grad.data_ptr()
+        for p in self.order:
+            o = 4 * self.offset[p]
+            if p.data_ptr() != base_p + o:
+                raise RuntimeError('a parameter was moved out of the flat buffer (module.to()/load with assign?)')
+            if p.grad is None or p.grad.data_ptr() != base_g + o:
+                raise RuntimeError('a gradient was detached from the flat buffer (zero_grad(set_to_none=True) or '
+                                   'p.grad = None); use the optimizer\'s / reducer\'s zero_grad()')
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) semantics on FlatBuffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError('FlatAdam: invalid hyper-parameter')
+        super(FlatAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.buffers = FlatBuffers([g['params'] for g in self.param_groups])
+        self.exp_avg = torch.zeros_like(self.buffers.param)
+        self.exp_avg_sq = torch.zeros_like(self.buffers.param)
+        self._steps = [0] * len(self.param_groups)
+        self._step_t = [torch.tensor(0.0) for _ in self.param_groups]  # one host tensor per group, shared by its params
+        for gi, group in enumerate(self.param_groups):
+            for p in group['params']:
+                if not p.requires_grad:
+                    continue
+                o, n = self.buffers.offset[p], p.numel()
+                self.state[p] = {'step': self._step_t[gi], 'exp_avg': self.exp_avg[o:o + n].view(p.shape),
+                                 'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape)}
+
+    def zero_grad(self, set_to_none=False):
+        self.buffers.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.buffers.check_bound()
+        for gi, (group, (s, e)) in enumerate(zip(self.param_groups, self.buffers.group_range)):
+            if e == s:
+                continue
+            self._steps[gi] += 1
+            t = self._steps[gi]
+            beta1, beta2 = group['betas']
+            bias_correction1 = 1 - beta1 ** t
+            bias_correction2 = 1 - beta2 ** t
+            step_size = group['lr'] / bias_correction1
+            RF.adam_step_(self.buffers.param[s:e], self.buffers.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
+                          step_size, beta1, beta2, group['eps'], group['weight_decay'], math.sqrt(bias_correction2))
+            self._step_t[gi].fill_(float(t))
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the state tensors by copies; copy them back into the flat moments."""
+        super(FlatAdam, self).load_state_dict(state_dict)
+        with torch.no_grad():
+            for gi, group in enumerate(self.param_groups):
+                for p in group['params']:
+                    st = self.state.get(p)
+                    if not st or not p.requires_grad:
+                        continue
+                    o, n = self.buffers.offset[p], p.numel()
+                    for name, flat in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                        view = flat[o:o + n].view(p.shape)
+                        view.copy_(st[name])
+                        st[name] = view
+                    self._steps[gi] = int(st['step'])
+                    st['step'] = self._step_t[gi]
+                self._step_t[gi].fill_(float(self._steps[gi]))

@@ -32,8 +32,12 @@ def import_reference():
                  'models.archs.dcn.deform_conv_cuda']:
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
-    for cls in ['SSIM', 'MS_SSIM', 'DISTS', 'LPIPSvgg']:
+    for cls in ['MS_SSIM', 'DISTS', 'LPIPSvgg']:
         setattr(sys.modules['IQA_pytorch'], cls, type(cls, (torch.nn.Module,), {}))
+    # IQA_pytorch is third-party and absent: its SSIM is the restatement in oracle/ssim_oracle.py (PARITY UNPINNED);
+    # it is only reached by the fixtures that say so (lf_mode='ssim')
+    from oracle.ssim_oracle import SSIM as oracle_ssim
+    sys.modules['IQA_pytorch'].SSIM = oracle_ssim
     sys.modules['torchvision.utils'].make_grid = lambda *a, **k: None
     sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
     import models.archs.dcn.deform_conv  # noqa: F401
@@ -315,8 +319,137 @@ def main_predeblur():
     save('edvr_predeblur', **arrs)
 
 
+def main_train_step():
+    """train_step.npz: the reference's OWN VideoSRModel (codes/models/VideoSR_AllPair_model_YCbCr_Split.py) built through
+    create_model(opt) on CPU (gpu_ids None), driven for 3 optimize_parameters() steps on one seeded batch: per-step
+    loss terms, gradient norm of the first step, and the parameters after the last step.
+      tag 'cb'   : cri_pix_y replaced by the reference's LapPyrLoss(3, 'cb', 'cb') -- every op in-tree => PINNED
+      tag 'ssim' : the model's own 'lappyr' criterion, LapPyrLoss(3, 'ssim', 'cb'), with IQA_pytorch.SSIM = the
+                   restatement in oracle/ssim_oracle.py => composition pinned, SSIM term UNPINNED
+    Both: cri_pix_c = GWLoss(w=4), pixel_weight_y 1.0, pixel_weight_c 0.5, Adam lr 1e-3 betas (0.9, 0.99)."""
+    EDVR_arch, loss_mod, util, dc = import_reference()
+    import models
+    net_opt = dict(which_model_G='EDVR', nf=16, nc=3, nframes=3, groups=4, front_RBs=1, back_RBs=1, center=None,
+                   predeblur=False, HR_in=False, w_TSA=True)
+    arrs = {}
+    for tag in ('cb', 'ssim'):
+        opt = {'model': 'VideoSR_AllPair_YCbCr_Split', 'dist': False, 'gpu_ids': None, 'is_train': True, 'scale': 4,
+               'augment': None, 'network_G': dict(net_opt), 'path': {'pretrain_model_G': None, 'strict_load': True},
+               'train': {'pixel_criterion_y': 'lappyr', 'pixel_weight_y': 1.0, 'pixel_criterion_c': 'gw',
+                         'pixel_weight_c': 0.5, 'weight_decay_G': 0, 'ft_tsa_only': 0, 'lr_G': 1e-3, 'beta1': 0.9,
+                         'beta2': 0.99, 'lr_scheme': 'MultiStepLR_Restart', 'lr_steps': [1000], 'restarts': None,
+                         'restart_weights': None, 'lr_gamma': 0.5, 'clear_state': None}}
+        torch.manual_seed(8)
+        model = models.create_model(opt)
+        net = model.netG.module if hasattr(model.netG, 'module') else model.netG
+        fill_state_dict(net, 808, offset_std=0.02)     # weights re-created from the seed by the tests (not stored)
+        if tag == 'cb':
+            model.cri_pix_y = loss_mod.LapPyrLoss(num_levels=3, lf_mode='cb', hf_mode='cb', reduction='mean')
+        gen = torch.Generator().manual_seed(81)
+        # 24x32 LR -> 96x128 HR: the low-pass band of the 3-level pyramid is 24x32 (>= the 11x11 SSIM window).
+        # Only the centre GT frame is read by the model (:178-184); the others are zeros and are not stored.
+        gt_c = torch.rand(2, 3, 96, 128, generator=gen)
+        GT = torch.zeros(2, 3, 3, 96, 128)
+        GT[:, 1] = gt_c
+        data = {'LQs': torch.rand(2, 3, 3, 24, 32, generator=gen), 'GT': GT}
+        if tag == 'cb':
+            arrs['LQs'], arrs['GT_center'] = data['LQs'].numpy(), gt_c.numpy()
+        logs = []
+        for step in range(1, 4):
+            model.feed_data(data)
+            model.optimize_parameters(step)
+            log = model.get_current_log()
+            logs.append([log['l_pix_y'], log['l_pix_c'], log['l_pix']])
+            if step == 1:
+                arrs[tag + '.gnorm1'] = np.float64(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item())
+        arrs[tag + '.logs'] = np.array(logs, dtype=np.float64)
+        for k, v in net.state_dict().items():
+            if tag == 'cb' or k.startswith(('conv_first', 'pcd_align.L1_dcnpack', 'tsa_fusion.sAtt_5', 'conv_last', 'upconv2.bias')):
+                arrs[tag + '.after.' + k] = v.detach().numpy().copy()
+        model.feed_data(data)
+        model.test()
+        arrs[tag + '.fake_H_y'] = model.fake_H[:, 0:1].numpy().copy()
+    save('train_step', **arrs)
+
+
+def main_config3():
+    """edvr_c3.npz: the architecture of BASELINE configs 3-5 (nf128, 7 frames, TSA, x4) through the reference's EDVR at
+    32x48 (back_RBs reduced to 2 to keep the CPU run short): output, loss, gradient norm and a few gradients.  Weights
+    from the seeded fill (too large to commit)."""
+    EDVR_arch, loss_mod, util, dc = import_reference()
+    torch.manual_seed(5)
+    kw = dict(nf=128, nframes=7, groups=8, front_RBs=5, back_RBs=2, w_TSA=True)
+    net = EDVR_arch.EDVR(nc=3, center=None, predeblur=False, HR_in=False, **kw)
+    fill_state_dict(net, 303, offset_std=0.03)
+    x = torch.rand(1, 7, 3, 32, 48, generator=torch.Generator().manual_seed(1234))
+    out = net(x)
+    gt = torch.rand(out.shape, generator=torch.Generator().manual_seed(1235))
+    l = loss_mod.LapPyrLoss(3, 'cb', 'cb', 'mean')(out[:, 0:1], gt[:, 0:1]) + loss_mod.GWLoss(w=4)(out[:, 1:3], gt[:, 1:3])
+    l.backward()
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters()))
+    params = dict(net.named_parameters())
+    keep = ['conv_first.weight', 'feature_extraction.4.conv2.weight', 'fea_L3_conv1.weight', 'pcd_align.L3_dcnpack.weight',
+            'pcd_align.L1_dcnpack.weight', 'pcd_align.L1_dcnpack.conv_offset_mask.bias', 'pcd_align.cas_dcnpack.bias',
+            'pcd_align.L2_offset_conv2.bias', 'tsa_fusion.tAtt_2.bias', 'tsa_fusion.sAtt_L2.bias', 'recon_trunk.0.conv1.bias',
+            'upconv2.bias', 'conv_last.weight']
+    grads = {'grad.' + k: params[k].grad.numpy().copy() for k in keep}
+    grads['grad.conv_first.weight'] = grads['grad.conv_first.weight'].copy()
+    # large weight gradients: keep a slice (first 8 output channels) to bound the file size
+    for k in list(grads):
+        if grads[k].ndim == 4 and grads[k].size > 40000:
+            grads[k] = grads[k][:8].copy()
+    save('edvr_c3', x=x.numpy(), out=out.detach().numpy(), gt=gt.numpy(), loss=np.float64(l.item()),
+         gnorm=np.float64(gnorm.item()), **{k: np.asarray(v) for k, v in kw.items()}, **grads)
+
+
+def main_losses2():
+    """losses2.npz: the remaining criteria of loss.py (HuberLoss, PyramidLoss 'hb') and the stand-alone pyramid helpers
+    conv_gauss / upsample (utils/util.py:503-516), values + gradients.  Plus LapPyrLoss(3,'ssim','cb') with the
+    restated SSIM (UNPINNED third-party term; the rest of the composition is the reference's)."""
+    EDVR_arch, loss_mod, util, dc = import_reference()
+    torch.manual_seed(17)
+    arrs = {}
+    x = torch.rand(2, 1, 48, 64, requires_grad=True)
+    y = torch.rand(2, 1, 48, 64)
+    x.data[0, 0, :4] = y[0, 0, :4] + 0.003     # inside Huber's quadratic zone (delta 0.01)
+    arrs['x'], arrs['y'] = x.detach().numpy().copy(), y.numpy()
+    for lname, crit in [('hb', loss_mod.HuberLoss()), ('hb_sum', loss_mod.HuberLoss(delta=0.05, reduction='sum')),
+                        ('pyr_gau_hb', loss_mod.PyramidLoss(3, 'gau', 'hb', 'mean')),
+                        ('pyr_lap_hb', loss_mod.PyramidLoss(2, 'lap', 'hb', 'mean')),
+                        ('lappyr_ssim_UNPINNED', loss_mod.LapPyrLoss(3, 'ssim', 'cb', 'mean'))]:
+        x.grad = None
+        l = crit(x, y)
+        l.backward()
+        arrs[lname] = np.float64(l.item())
+        arrs['g_' + lname] = x.grad.numpy().copy()
+    for tag, C, H, W in (('a', 3, 20, 28), ('b', 1, 6, 8)):
+        img = torch.rand(2, C, H, W, requires_grad=True)
+        k = util.gauss_kernel(channels=C)
+        for fname, fn in (('conv_gauss', lambda t: util.conv_gauss(t, k)), ('conv_gauss4', lambda t: util.conv_gauss(t, 4 * k)),
+                          ('upsample', util.upsample)):
+            img.grad = None
+            out = fn(img)
+            gout = torch.randn(out.shape)
+            out.backward(gout)
+            arrs['%s_%s.in' % (fname, tag)] = img.detach().numpy().copy()
+            arrs['%s_%s.out' % (fname, tag)] = out.detach().numpy().copy()
+            arrs['%s_%s.gout' % (fname, tag)] = gout.numpy()
+            arrs['%s_%s.gin' % (fname, tag)] = img.grad.numpy().copy()
+        ii = torch.randint(0, 16, (1, C, H, W)).float()
+        arrs['int_%s.in' % tag] = ii.numpy()
+        arrs['int_%s.conv_gauss' % tag] = util.conv_gauss(ii, k).numpy()
+        arrs['int_%s.upsample' % tag] = util.upsample(ii).numpy()
+    save('losses2', **arrs)
+
+
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('all', 'train_step'):
+        main_train_step()
+    if which in ('all', 'config3'):
+        main_config3()
+    if which in ('all', 'losses2'):
+        main_losses2()
     if which in ('all', 'predeblur'):
         main_predeblur()
     if which in ('all', 'augment'):

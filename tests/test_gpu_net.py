@@ -160,3 +160,30 @@ def test_edvr_predeblur_and_hr_in_fixture(gemm_mode, tag, kw):
     for k in g:
         if k.startswith(tag + '.grad.'):
             gcheck(gemm_mode, k, params[k[len(tag) + 6:]].grad, torch.from_numpy(g[k]), TOL_G)
+
+
+def test_config3_arch_fixture(gemm_mode):
+    """The architecture of BASELINE configs 3-5 (nf128, 7 frames, groups 8 => 16 channels per deformable group, TSA, x4)
+    against the reference's EDVR (edvr_c3.npz; 32x48 LR, back_RBs 2): output, LapPyr(cb,cb) + GWLoss value, gradient
+    norm and a spread of gradients (first conv, feature pyramid, every DCN level, TSA, trunk, tail)."""
+    TOL, _, TOL_P = TOLS[gemm_mode]
+    from weights import fill_state_dict
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    from realvsr_amd import loss as L
+    g = load_golden('edvr_c3')
+    net = EDVR(nf=128, nc=3, nframes=7, groups=8, front_RBs=5, back_RBs=2, w_TSA=True)
+    fill_state_dict(net, 303, offset_std=0.03)
+    net = net.to(dev())
+    out = net(_t(g, 'x'))
+    check('out', out, torch.from_numpy(g['out']), TOL)
+    gt = _t(g, 'gt')
+    loss = L.LapPyrLoss(3, 'cb', 'cb', 'mean')(out[:, 0:1], gt[:, 0:1]) + L.GWLoss(w=4)(out[:, 1:3], gt[:, 1:3])
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= (1e-5 if gemm_mode == 'f32' else 1e-4) * abs(float(g['loss']))
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item()
+    assert abs(gnorm - float(g['gnorm'])) <= (1e-3 if gemm_mode == 'f32' else 5e-3) * float(g['gnorm']), (gnorm, float(g['gnorm']))
+    params = dict(net.named_parameters())
+    for k in [k for k in g if k.startswith('grad.')]:
+        ref = torch.from_numpy(g[k])
+        got = params[k[5:]].grad
+        gcheck(gemm_mode, k, got[:ref.shape[0]] if got.shape != ref.shape else got, ref, TOL_P)

@@ -42,7 +42,13 @@ def test_operators_refuse_cpu_tensors():
     with pytest.raises(NotImplementedError):
         L.LapPyrLoss(3, 'cb', 'cb')(torch.rand(1, 1, 16, 16), torch.rand(1, 1, 16, 16))
     with pytest.raises(NotImplementedError):
-        L.LapPyrLoss(3, 'ssim', 'cb')  # IQA_pytorch is not vendored by the reference: parity unpinned
+        L.LapPyrLoss(3, 'ssim', 'cb')(torch.rand(1, 1, 64, 64), torch.rand(1, 1, 64, 64))
+    with pytest.raises(NotImplementedError):
+        L.PyramidLoss(3, 'gau', 'hb')(torch.rand(1, 1, 16, 16), torch.rand(1, 1, 16, 16))
+    with pytest.raises(ValueError):
+        L.LapPyrLoss(3, 'l1', 'cb')      # loss.py:205-206
+    with pytest.raises(ValueError):
+        L.PyramidLoss(3, 'gau', 'ssim')  # loss.py:176-177
 
 
 def test_state_dict_schema_matches_reference():
@@ -73,3 +79,36 @@ def test_define_g():
     assert isinstance(tdan, TDAN)
     with pytest.raises(NotImplementedError):
         define_G({'network_G': {'which_model_G': 'RCAN'}})
+
+
+def test_create_model_refuses_cpu_and_unknown_models():
+    from realvsr_amd.VideoSR_model import create_model
+    opt = {'model': 'VideoSR_AllPair_YCbCr_Split', 'gpu_ids': None, 'is_train': True, 'dist': False,
+           'network_G': {'which_model_G': 'EDVR', 'nf': 16, 'nc': 3, 'nframes': 3, 'groups': 4, 'front_RBs': 1,
+                         'back_RBs': 1, 'w_TSA': True}}
+    with pytest.raises(NotImplementedError):
+        create_model(opt)                     # no CPU path
+    with pytest.raises(NotImplementedError):
+        create_model(dict(opt, model='VideoSRGAN_AllPair_YCbCr_Split'))
+
+
+def test_flat_buffers_layout_and_guards():
+    """optim.FlatBuffers: parameters and gradients become views of two identically laid-out buffers (CPU tensors are
+    fine for the layout logic); re-binding a gradient is detected."""
+    from realvsr_amd.optim import FlatBuffers
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Conv2d(5, 2, 1))
+    before = [p.detach().clone() for p in net.parameters()]
+    fb = FlatBuffers([list(net.parameters())])
+    assert fb.order[0] is list(net.parameters())[-1]          # reverse registration order
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b)
+        assert fb.offset[p] % 64 == 0
+        assert p.data_ptr() == fb.param.data_ptr() + 4 * fb.offset[p]
+        assert p.grad.data_ptr() == fb.grad.data_ptr() + 4 * fb.offset[p]
+    net(torch.randn(2, 3, 6, 6)).sum().backward()
+    assert float(fb.grad.abs().sum()) > 0                      # autograd accumulated into the views
+    fb.check_bound()
+    net.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        fb.check_bound()

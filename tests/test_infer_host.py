@@ -59,28 +59,50 @@ def test_tdan_state_dict_schema_matches_reference():
         assert sorted(net.state_dict().keys()) == [str(k) for k in g[tag + '.keys']]
 
 
-def test_augment_matches_reference_under_seeds():
-    """same numpy-RNG call order as data/augments_video_allpair.py -> same boxes/permutations."""
+def _apply_plan_numpy(a, b, plan):
+    """What rvsr_augment_clips computes, in numpy (box paste + channel permutation; no blend)."""
+    a, b = a[..., list(plan.perm), :, :], b[..., list(plan.perm), :, :]
+    y0, y1, x0, x1 = plan.box
+    o2 = b.copy()
+    if plan.box_mode == 1:
+        o2[..., y0:y1, x0:x1] = a[..., y0:y1, x0:x1]
+    elif plan.box_mode == 2:
+        o2 = a.copy()
+        o2[..., y0:y1, x0:x1] = b[..., y0:y1, x0:x1]
+    return a, o2
+
+
+def test_augment_plans_match_reference_under_seeds():
+    """draw_plan consumes numpy's RNG in the call order of data/augments_video_allpair.py,
+    so a seeded run picks the reference's boxes / permutations (the fixture holds the reference's outputs; the device
+    kernel that applies a plan is checked against the same fixture in tests/test_gpu_train.py)."""
     from realvsr_amd import augment
     g = load_golden('augment')
-    t = lambda k: torch.from_numpy(g[k].copy())
     for seed in range(6):
         np.random.seed(100 + seed)
-        o1, o2 = augment.cutblur(t('a4'), t('b4'), prob=1.0, alpha=0.7)
-        assert np.array_equal(o1.numpy(), g['cutblur%d.1' % seed]) and np.array_equal(o2.numpy(), g['cutblur%d.2' % seed])
+        plan = augment.AugPlan()
+        augment._draw_cutblur(plan, g['a4'].shape, 1.0, 0.7)
+        o1, o2 = _apply_plan_numpy(g['a4'], g['b4'], plan)
+        assert plan.fired and np.array_equal(o1, g['cutblur%d.1' % seed]) and np.array_equal(o2, g['cutblur%d.2' % seed])
     for seed in range(3):
         np.random.seed(200 + seed)
-        o1, o2 = augment.rgb(t('a5'), t('b5'), prob=1.0)
-        assert np.array_equal(o1.numpy(), g['rgb%d.1' % seed]) and np.array_equal(o2.numpy(), g['rgb%d.2' % seed])
+        plan = augment.AugPlan()
+        augment._draw_rgb(plan, 1.0)
+        o1, o2 = _apply_plan_numpy(g['a5'], g['b5'], plan)
+        assert np.array_equal(o1, g['rgb%d.1' % seed]) and np.array_equal(o2, g['rgb%d.2' % seed])
     for seed in range(6):
         np.random.seed(300 + seed)
-        o1, o2 = augment.apply_augment(t('a5'), t('b5'), ['none', 'cutblur', 'rgb'], [1.0, 1.0, 1.0], [1.0, 0.7, 1.0],
-                                       mix_p=[0.2, 0.5, 0.3])
-        assert np.array_equal(o1.numpy(), g['mix%d.1' % seed]) and np.array_equal(o2.numpy(), g['mix%d.2' % seed])
+        plan = augment.draw_plan(g['a5'].shape, ['none', 'cutblur', 'rgb'], [1.0, 1.0, 1.0], [1.0, 0.7, 1.0], mix_p=[0.2, 0.5, 0.3])
+        o1, o2 = _apply_plan_numpy(g['a5'], g['b5'], plan)
+        assert np.array_equal(o1, g['mix%d.1' % seed]) and np.array_equal(o2, g['mix%d.2' % seed])
     with pytest.raises(ValueError):
         augment.cutblur(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 4))
     with pytest.raises(ValueError):
-        augment.apply_augment(t('a5'), t('b5'), ['mixup'], [1.0], [1.0])
+        augment.draw_plan((2, 3, 3, 12, 16), ['mixup'], [1.0], [1.0])
+    np.random.seed(5)
+    assert not augment.draw_plan((2, 3, 3, 12, 16), ['cutblur'], [0.0], [0.7]).fired    # prob 0 never fires
+    with pytest.raises(NotImplementedError):
+        augment.rgb(torch.zeros(1, 1, 3, 8, 8), torch.zeros(1, 1, 3, 8, 8))            # device op: CPU tensors refused
 
 
 def test_edvr_predeblur_hr_in_schema_matches_reference():
