@@ -31,48 +31,7 @@ extern "C" int rvsr_debug_read_dcn(unsigned long long* out) { return (int)hipMem
 #define DSTAMP_W3(i) do {} while (0)
 #endif
 
-#define D2_R 3  // halo radius (pixels) of the LDS x tile beyond the 3x3 footprint
-
-// Stage the x tile of NQ channel quads (channels c0 .. c0+4*NQ-1) into LDS as [quad][row][col] float4.
-// All global loads are unconditional (addresses clamped into the tensor, validity applied afterwards) and are
-// issued in batches before any LDS write: a load inside a divergent `if` is waited for at the join, which turns
-// the staging loop into one HBM/L2 round trip per item.
-template <int NT, int NQ, int TR, int TC>
-__device__ __forceinline__ void stage_x_tile(float4* xt, const DcnGeom& d, int b, int c0, int ty0, int tx0, int tid) {
-    constexpr int NPOS = TR * TC, NITEMS = NQ * NPOS, PER = (NITEMS + NT - 1) / NT, BATCH = PER < 6 ? PER : 5;
-    const size_t HW = (size_t)d.H * d.W;
-#pragma unroll
-    for (int base = 0; base < PER; base += BATCH) {
-        float v[BATCH][4];
-        int nv[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int it_raw = tid + (base + k) * NT;
-            const bool live = (base + k < PER) && it_raw < NITEMS;
-            const int it = live ? it_raw : 0;
-            const int quad = it / NPOS, pos = it - quad * NPOS;
-            const int r = pos / TC, s = pos - r * TC;
-            const int gy = ty0 + r, gx = tx0 + s, cb = c0 + 4 * quad;
-            const bool inb = live && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W && cb < d.C;
-            const int gyc = gy < 0 ? 0 : (gy >= d.H ? d.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= d.W ? d.W - 1 : gx);
-            const int cbc = inb ? cb : 0;
-            const float* src = d.x + ((size_t)b * d.C) * HW + (size_t)gyc * d.W + gxc;
-            nv[k] = inb ? (d.C - cb < 4 ? d.C - cb : 4) : 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = cbc + e < d.C ? cbc + e : d.C - 1;
-                v[k][e] = src[(size_t)c * HW];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int it = tid + (base + k) * NT;
-            if ((base + k < PER) && it < NITEMS)
-                xt[it] = make_float4(nv[k] > 0 ? v[k][0] : 0.f, nv[k] > 1 ? v[k][1] : 0.f, nv[k] > 2 ? v[k][2] : 0.f,
-                                     nv[k] > 3 ? v[k][3] : 0.f);
-        }
-    }
-}
+#include "dcn_tile.h"
 
 template <int TH, int MT>
 __global__ __launch_bounds__(TH * 64, MT <= 2 ? 4 : 2) void dcn_fwd2_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
@@ -270,6 +229,11 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, d.Co,
                        d.C, 9, mt * 32, 1, nchunks, nmb, 0);
     const bf16x8* wp = (const bf16x8*)workspace;
+    static const int gen = [] { const char* e = getenv("RVSR_DCN_FWD"); return e ? atoi(e) : 3; }();  // developer A/B switch
+    if (gen >= 3) {
+        const int rc = rvsr_launch_dcn_fwd3(p, workspace, mt, st);
+        if (rc != RVSR_ERR_UNSUPPORTED) return rc;
+    }
     if (mt == 1) return launch_dcn_fwd2<8, 1>(p, wp, st);
     if (mt == 2) return launch_dcn_fwd2<8, 2>(p, wp, st);
     return launch_dcn_fwd2<8, 4>(p, wp, st);

@@ -1,0 +1,274 @@
+// dcn3_kernels.hip -- fused modulated-DCN forward, third generation (gfx950).
+//
+// Same decomposition as dcn_fwd2_kernel (dcn2_kernels.hip): out[Co, px] = W[Co, (tap, c)] * col[(tap, c), px] with the
+// column values built by the lane the matrix core expects them from, never stored anywhere.  What changed follows
+// the SQ counters of the second generation (profiles/r02_dcn_pmc.md): 188 VALU instructions per wave and k-step
+// against 6 MFMAs, 43 % of the wave time parked in s_waitcnt/s_barrier around two serial staging round trips per
+// 16-channel chunk.
+//   * The LDS x tile is ZERO outside the image, so every validity rule of the reference's bilinear sampler
+//     (kernel.cu:467-497: corners outside [0,H-1]x[0,W-1] contribute 0; whole sample 0 unless -1 < y < H, -1 < x < W,
+//     :618) is implied by reading the tile: a sample whose 2x2 footprint lies inside the tile needs no per-corner
+//     masks, clamps or range tests at all -- one unsigned compare per axis decides "inside the tile".
+//   * Sampling runs in tile coordinates; the modulation mask is folded into the row weights (6 multiplies/subtracts
+//     for the four corner weights instead of 4 + 8), sigmoid uses v_exp/v_rcp directly.
+//   * Weight slice and x tile of a chunk are requested together (one L2/HBM round trip per chunk, not two).
+//   * Samples that leave the tile (|offset| > R) still fall back to per-lane global gathers with the full rule set.
+// Geometry: stride 1, dilation 1, groups of >= 8 channels (what EDVR / TDAN instantiate); everything else keeps the
+// second-generation kernel.
+#include "dcn_tile.h"
+
+#ifdef RVSR_TIMELINE_DCN
+__device__ unsigned long long rvsr_dbg_dcn3[256];
+extern "C" int rvsr_debug_read_dcn3(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_dcn3), sizeof(unsigned long long) * 256); }
+#define TSTAMP(i) do { if (blockIdx.x == 77 && blockIdx.z == 1 && threadIdx.x == 0) rvsr_dbg_dcn3[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
+
+// The x tile of a 16-channel chunk for an 8 x 32 pixel workgroup: 16 rows x 40 columns x 4 channel quads = 2560 float4
+// items = 5 per thread of a 512-thread workgroup.  Item decode is shifts and masks only and four of the five items
+// share one address (same position, consecutive quads): the staging of the second generation spent ~9 K cycles per
+// chunk just ISSUING its loads (div/mod by 40 and 640, 64-bit address chains) next to co-resident waves in their
+// VALU-bound tap loops.
+//   items 0..3: position (row tid >> 5, column tid & 31), quad j
+//   item  4   : position (row (tid >> 3) & 15, column 32 + (tid & 7)), quad tid >> 7
+struct XTile16x40 {
+    float v[5][4];
+    bool inb0, inb4;
+};
+__device__ __forceinline__ void xtile16x40_load(XTile16x40& r, const DcnGeom& d, int b, int c0, int ty0, int tx0, int tid) {
+    const unsigned HW = (unsigned)(d.H * d.W);
+    const float* base = d.x + (size_t)b * d.C * HW;   // uniform; per-lane offsets below are 32-bit
+    {
+        const int gy = ty0 + (tid >> 5), gx = tx0 + (tid & 31);
+        r.inb0 = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        const int gyc = gy < 0 ? 0 : (gy >= d.H ? d.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= d.W ? d.W - 1 : gx);
+        const unsigned off = (unsigned)(gyc * d.W + gxc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + 4 * j + e;
+                r.v[j][e] = base[(unsigned)(c < d.C ? c : d.C - 1) * HW + off];
+            }
+    }
+    {
+        const int gy = ty0 + ((tid >> 3) & 15), gx = tx0 + 32 + (tid & 7), q = tid >> 7;
+        r.inb4 = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        const int gyc = gy < 0 ? 0 : (gy >= d.H ? d.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= d.W ? d.W - 1 : gx);
+        const unsigned off = (unsigned)(gyc * d.W + gxc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + 4 * q + e;
+            r.v[4][e] = base[(unsigned)(c < d.C ? c : d.C - 1) * HW + off];
+        }
+    }
+}
+// zero outside the image and beyond the last channel: the tap loop relies on it
+__device__ __forceinline__ void xtile16x40_commit(float4* xt, const XTile16x40& r, const DcnGeom& d, int c0, int tid) {
+    constexpr int TC = 40, NPOS = 16 * 40;
+    const int p0 = (tid >> 5) * TC + (tid & 31);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int left = r.inb0 ? d.C - (c0 + 4 * j) : 0;
+        xt[j * NPOS + p0] = make_float4(left > 0 ? r.v[j][0] : 0.f, left > 1 ? r.v[j][1] : 0.f, left > 2 ? r.v[j][2] : 0.f,
+                                        left > 3 ? r.v[j][3] : 0.f);
+    }
+    const int q = tid >> 7, p4 = ((tid >> 3) & 15) * TC + 32 + (tid & 7);
+    const int left = r.inb4 ? d.C - (c0 + 4 * q) : 0;
+    xt[q * NPOS + p4] = make_float4(left > 0 ? r.v[4][0] : 0.f, left > 1 ? r.v[4][1] : 0.f, left > 2 ? r.v[4][2] : 0.f,
+                                    left > 3 ? r.v[4][3] : 0.f);
+}
+
+template <int MT>
+__global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
+    constexpr int TH = 8, NT = TH * 64;
+    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    constexpr int MP = MT * 32, WVEC = 9 * 2 * MP;  // 16-byte vectors per weight part
+    constexpr int NWV = (2 * WVEC + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);           // [2 octets][2 halves][NPOS], zero outside the image
+    bf16x8* ws_hi = reinterpret_cast<bf16x8*>(xt + 4 * NPOS);   // [9 taps][2 octets][MP]
+    bf16x8* ws_lo = ws_hi + WVEC;
+    float* bias_s = reinterpret_cast<float*>(ws_lo + WVEC);     // [MP]
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    unsigned sbx, sby, sbz;
+    swizzled_block(sbx, sby, sbz, d.swz);
+    const int tx = sbx % d.ntx, ty = sbx / d.ntx;
+    const int x0 = tx * 32, y0 = ty * TH, mb = sby, b = sbz;
+    const int ty0 = y0 - d.pad - D2_R, tx0 = x0 - d.pad - D2_R;  // image coords of tile (0,0); stride 1
+    const int nchunks = (d.C + 15) / 16;
+    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int oy = y0 + wave, ox = x0 + lo;
+    const bool px_ok = oy < d.Ho && ox < d.Wo;
+    const size_t pix = (size_t)oy * d.Wo + ox;
+    // Sample positions are formed in IMAGE coordinates exactly as the reference does (float(h_in + i) + offset,
+    // kernel.cu:594-616) so that floor() and the fractional weights round identically; only the integer corner is
+    // moved into tile coordinates.
+    const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = zero16();
+
+    TSTAMP(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * 16;
+        const int cb8 = c0 + 8 * hi;              // first channel of this lane's octet
+        const bool oct_ok = px_ok && cb8 < d.C;
+        const int g = oct_ok ? cb8 / d.cpg : 0;
+        const size_t pixc = oct_ok ? pix : 0;     // lanes without work read pixel 0 (loads stay unconditional)
+        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pixc;
+        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pixc;
+        float n_dy = offp[0], n_dx = offp[hw], n_m = mskp[0];
+        {   // weight slice + x tile of the chunk: ALL global loads first, then the LDS writes (one round trip)
+            const bf16x8* src = wpack + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
+            bf16x8 wv[NWV];
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int e = tid + i * NT;
+                wv[i] = src[e < 2 * WVEC ? e : 0];
+            }
+            static_assert(TR == 16 && TC == 40 && NT == 512, "xtile16x40 is written for this tile");
+            XTile16x40 xr;
+            xtile16x40_load(xr, d, b, c0, ty0, tx0, tid);
+            TSTAMP(1 + 6 * chunk);
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                const int e = tid + i * NT;
+                if (e < 2 * WVEC) ws_hi[e] = wv[i];
+            }
+            TSTAMP(2 + 6 * chunk);
+            xtile16x40_commit(xt, xr, d, c0, tid);
+            TSTAMP(3 + 6 * chunk);
+            if (chunk == 0 && tid < MP) {
+                const int o = mb * MP + tid;
+                bias_s[tid] = (p.bias != nullptr && o < d.Co) ? p.bias[o] : 0.f;
+            }
+        }
+        __syncthreads();
+        TSTAMP(4 + 6 * chunk);
+
+        const float4* xq0 = xt + (2 * hi) * NPOS;  // channels cb8..cb8+3 (xq0[NPOS + pos]: cb8+4..cb8+7)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float dy = n_dy, dx = n_dx;
+            float m = n_m;
+            if (tap < 8) {  // (compile-time) prefetch the next tap's offsets/mask under this tap's math
+                n_dy = offp[(size_t)(2 * tap + 2) * hw];
+                n_dx = offp[(size_t)(2 * tap + 3) * hw];
+                n_m = mskp[(size_t)(tap + 1) * hw];
+            }
+            if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));  // (uniform)
+            m = oct_ok ? m : 0.f;                                            // lanes without work contribute zeros
+            const float yr = (by + (float)(tap / 3)) + dy, xr_ = (bx + (float)(tap % 3)) + dx;
+            const float fy = floorf(yr), fx = floorf(xr_);
+            const int r0 = (int)fy - ty0, s0 = (int)fx - tx0;   // tile coordinates of the top-left corner
+            const float ly = yr - fy, lx = xr_ - fx;
+            // 2x2 footprint inside the tile <=> 0 <= r0 <= TR-2 and 0 <= s0 <= TC-2 (NaN/huge offsets fail the test)
+            const bool in_tile = (unsigned)r0 < (unsigned)(TR - 1) && (unsigned)s0 < (unsigned)(TC - 1);
+            const float wy1 = ly * m, wy0 = m - wy1;
+            const float w01 = wy0 * lx, w00 = wy0 - w01, w11 = wy1 * lx, w10 = wy1 - w11;
+            const int pos = in_tile ? r0 * TC + s0 : 0;
+            const float4 a00 = xq0[pos], b00 = xq0[NPOS + pos], a01 = xq0[pos + 1], b01 = xq0[NPOS + pos + 1];
+            const float4 a10 = xq0[pos + TC], b10 = xq0[NPOS + pos + TC], a11 = xq0[pos + TC + 1], b11 = xq0[NPOS + pos + TC + 1];
+            float v[8];
+            v[0] = w00 * a00.x + w01 * a01.x + w10 * a10.x + w11 * a11.x;
+            v[1] = w00 * a00.y + w01 * a01.y + w10 * a10.y + w11 * a11.y;
+            v[2] = w00 * a00.z + w01 * a01.z + w10 * a10.z + w11 * a11.z;
+            v[3] = w00 * a00.w + w01 * a01.w + w10 * a10.w + w11 * a11.w;
+            v[4] = w00 * b00.x + w01 * b01.x + w10 * b10.x + w11 * b11.x;
+            v[5] = w00 * b00.y + w01 * b01.y + w10 * b10.y + w11 * b11.y;
+            v[6] = w00 * b00.z + w01 * b01.z + w10 * b10.z + w11 * b11.z;
+            v[7] = w00 * b00.w + w01 * b01.w + w10 * b10.w + w11 * b11.w;
+            if (!in_tile && oct_ok) {
+                // large offset: this lane gathers its corners from global memory, with the reference's rules spelled out
+                // (image coordinates; kernel.cu:467-497,618)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                const float y = yr, x = xr_;
+                if (y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W) {
+                    const float gy_ = floorf(y), gx_ = floorf(x);
+                    const int yi = (int)gy_, xi = (int)gx_;
+                    const float qy = y - gy_, qx = x - gx_, py = 1.f - qy, px = 1.f - qx;
+                    const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                    const float u00 = (vy0 && vx0) ? py * px * m : 0.f, u01 = (vy0 && vx1) ? py * qx * m : 0.f;
+                    const float u10 = (vy1 && vx0) ? qy * px * m : 0.f, u11 = (vy1 && vx1) ? qy * qx * m : 0.f;
+                    const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1;
+                    const int cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                    const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                    const float* pl = d.x + ((size_t)b * d.C + cb8) * HW;
+                    float q00[8], q01[8], q10[8], q11[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {   // all 32 loads in flight together (channel clamped, masked below)
+                        const float* q = pl + (size_t)(cb8 + j < d.C ? j : 0) * HW;
+                        q00[j] = q[i00]; q01[j] = q[i01]; q10[j] = q[i10]; q11[j] = q[i11];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        v[j] = cb8 + j < d.C ? u00 * q00[j] + u01 * q01[j] + u10 * q10[j] + u11 * q11[j] : 0.f;
+                }
+            }
+            bf16x8 bh, bl;
+            split8(v, bh, bl);
+            bf16x8 ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[mt] = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
+                al[mt] = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bh, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bl, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
+            if (chunk == 1) TSTAMP(40 + tap);
+        }
+        TSTAMP(5 + 6 * chunk);
+        __syncthreads();
+        TSTAMP(6 + 6 * chunk);
+    }
+
+    if (oy >= d.Ho) return;
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ol = mt * 32 + drow(r, hi);
+            const int o = mb * MP + ol;
+            const bool ok = ox < d.Wo && o < d.Co;
+            const int oc = ok ? o : 0;
+            float v = acc[mt][r] + bias_s[ol];
+            v = v > 0.f ? v : v * neg;
+            if (ok) p.out[((size_t)b * d.Co + oc) * hw + pix] = v;
+        }
+    }
+    TSTAMP(30);
+}
+
+template <int MT>
+static int launch_dcn_fwd3(const DcnFwdParams& p, const bf16x8* wpack, hipStream_t st) {
+    constexpr int TH = 8, TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    const size_t lds = (size_t)16 * (4 * TR * TC + 2 * 9 * 2 * MT * 32) + sizeof(float) * MT * 32;
+    auto k = dcn_fwd3_kernel<MT>;
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd3: cannot reserve %zu B of LDS", lds);
+    const DcnGeom& d = p.d;
+    dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), (d.Co + MT * 32 - 1) / (MT * 32), d.B);
+    hipLaunchKernelGGL(k, grid, dim3(TH * 64), lds, st, p, wpack);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd3 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+// `wpack`: the image pack_weights_kernel(mode 0, CCG 1) wrote for (mt, nchunks, nmb) -- built by rvsr_launch_dcn_fwd2's caller
+int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st) {
+    const DcnGeom& d = p.d;
+    if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
+    const bf16x8* wp = (const bf16x8*)wpack;
+    if (mt == 1) return launch_dcn_fwd3<1>(p, wp, st);
+    if (mt == 2) return launch_dcn_fwd3<2>(p, wp, st);
+    return launch_dcn_fwd3<4>(p, wp, st);
+}

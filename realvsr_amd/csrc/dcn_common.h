@@ -82,6 +82,8 @@ struct DcnFwdParams {
 // bf16x3 forward (dcn2_kernels.hip); returns RVSR_ERR_UNSUPPORTED if the geometry is not covered
 size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st);
+// third-generation forward (dcn3_kernels.hip): consumes the weight image rvsr_launch_dcn_fwd2 packs; stride 1, dilation 1
+int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st);
 size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);

@@ -456,7 +456,8 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         p.d = d; p.w = weight; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
         const int CoP = (d.Co + 1) & ~1;
         const size_t lds = sizeof(float) * ((size_t)CoP * DCN_NPX + (size_t)CoP * DCN_KC + DCN_KC * DCN_NPX + DCN_CC * 14 * 42);
-        if (lds > 160 * 1024) FAIL(RVSR_ERR_UNSUPPORTED, "dcn backward: channels_out %d needs %zu B of LDS", d.Co, lds);
+        // (the LDS bound belongs to the first-generation kernel only: checked where that kernel is actually launched)
+        if (rc2 != RVSR_OK && lds > 160 * 1024) FAIL(RVSR_ERR_UNSUPPORTED, "dcn backward: channels_out %d needs %zu B of LDS", d.Co, lds);
         if (rc2 == RVSR_OK) {
             // done by the second-generation kernel
         } else if (d.cpg % DCN_CC == 0) {

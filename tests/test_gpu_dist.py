@@ -70,7 +70,8 @@ def _worker(rank, world, port, q):
         model.optimize_parameters(step)
         if step == 1:
             grads = model.optimizer_G.buffers.grad.detach().cpu().clone()
-    q.put((rank, grads, model.optimizer_G.buffers.param.detach().cpu().clone(), model.get_current_log()['l_pix']))
+    # numpy payloads: torch tensors travel through an fd-sharing side channel that dies with this process
+    q.put((rank, grads.numpy(), model.optimizer_G.buffers.param.detach().cpu().numpy(), model.get_current_log()['l_pix']))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,7 +86,7 @@ def test_two_ranks_one_gpu_match_full_batch():
     got = {}
     for _ in range(world):
         r, grads, params, l = q.get(timeout=600)
-        got[r] = (grads, params, l)
+        got[r] = (torch.from_numpy(grads), torch.from_numpy(params), l)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
