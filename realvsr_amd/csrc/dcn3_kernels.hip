@@ -123,22 +123,20 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
         const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pixc;
         float n_dy = offp[0], n_dx = offp[hw], n_m = mskp[0];
         {   // weight slice + x tile of the chunk: ALL global loads first, then the LDS writes (one round trip)
+            // weight slice: LDS-DMA (global_load_lds_dwordx4: lane l of a wave lands at M0 + 16 l, so a linear copy needs
+            // no registers, no ds_write and no wait before the barrier's)
             const bf16x8* src = wpack + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
-            bf16x8 wv[NWV];
 #pragma unroll
             for (int i = 0; i < NWV; ++i) {
                 const int e = tid + i * NT;
-                wv[i] = src[e < 2 * WVEC ? e : 0];
+                if (e - lane + 63 < 2 * WVEC)   // (wave-uniform; 2 * WVEC is a multiple of 64)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e),
+                                                     (__attribute__((address_space(3))) void*)(ws_hi + e), 16, 0, 0);
             }
             static_assert(TR == 16 && TC == 40 && NT == 512, "xtile16x40 is written for this tile");
             XTile16x40 xr;
             xtile16x40_load(xr, d, b, c0, ty0, tx0, tid);
             TSTAMP(1 + 6 * chunk);
-#pragma unroll
-            for (int i = 0; i < NWV; ++i) {
-                const int e = tid + i * NT;
-                if (e < 2 * WVEC) ws_hi[e] = wv[i];
-            }
             TSTAMP(2 + 6 * chunk);
             xtile16x40_commit(xt, xr, d, c0, tid);
             TSTAMP(3 + 6 * chunk);
@@ -147,6 +145,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
                 bias_s[tid] = (p.bias != nullptr && o < d.Co) ? p.bias[o] : 0.f;
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of this wave has landed
         __syncthreads();
         TSTAMP(4 + 6 * chunk);
 
@@ -233,17 +232,40 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
 
     if (oy >= d.Ho) return;
     const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+    if ((d.Wo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0) {   // (uniform)
+        // 16-byte stores: a 4x4 transpose inside every quad of lanes turns "lane = pixel, 4 registers = 4 consecutive channels"
+        // into "lane = channel, 4 consecutive pixels" (dword stores are store-issue-bound: 32 per lane, ~7.5 K cycles per tile)
+        const int j = lo & 3, col4 = x0 + (lo & ~3);
+        const bool col_ok = col4 < d.Wo;   // Wo % 4 == 0: the float4 is entirely inside or outside
+        const size_t pix4 = (size_t)oy * d.Wo + col4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ol = mt * 32 + drow(r, hi);
-            const int o = mb * MP + ol;
-            const bool ok = ox < d.Wo && o < d.Co;
-            const int oc = ok ? o : 0;
-            float v = acc[mt][r] + bias_s[ol];
-            v = v > 0.f ? v : v * neg;
-            if (ok) p.out[((size_t)b * d.Co + oc) * hw + pix] = v;
+            for (int rg = 0; rg < 4; ++rg) {
+                float r0 = acc[mt][4 * rg + 0], r1 = acc[mt][4 * rg + 1], r2 = acc[mt][4 * rg + 2], r3 = acc[mt][4 * rg + 3];
+                quad_transpose4(r0, r1, r2, r3, lo);
+                const int ol = mt * 32 + 8 * rg + 4 * hi + j;
+                const int o = mb * MP + ol;
+                const float bb = bias_s[ol];
+                float4 v = make_float4(r0 + bb, r1 + bb, r2 + bb, r3 + bb);
+                v.x = v.x > 0.f ? v.x : v.x * neg; v.y = v.y > 0.f ? v.y : v.y * neg;
+                v.z = v.z > 0.f ? v.z : v.z * neg; v.w = v.w > 0.f ? v.w : v.w * neg;
+                if (col_ok && o < d.Co) *reinterpret_cast<float4*>(p.out + ((size_t)b * d.Co + o) * hw + pix4) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ol = mt * 32 + drow(r, hi);
+                const int o = mb * MP + ol;
+                const bool ok = ox < d.Wo && o < d.Co;
+                const int oc = ok ? o : 0;
+                float v = acc[mt][r] + bias_s[ol];
+                v = v > 0.f ? v : v * neg;
+                if (ok) p.out[((size_t)b * d.Co + oc) * hw + pix] = v;
+            }
         }
     }
     TSTAMP(30);

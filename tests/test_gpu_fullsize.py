@@ -88,3 +88,121 @@ def test_dcn_with_zero_offsets_is_the_plain_conv(gemm_mode):
     lhs = float(msk.grad.double().sum())
     rhs = float((gout.double() * (yc.detach().double() - conv.bias.detach().view(1, -1, 1, 1).double())).sum())
     assert abs(lhs - rhs) <= 1e-4 * abs(rhs) + 1e-3, (lhs, rhs)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BASELINE config 3 (nf128, 7 frames, batch 16: 112 frames of 128 x 180 x 320 in the per-frame / alignment stage)
+# and config 5 (nf128, 7 frames, 540 x 960 LR, forward only): the same properties at those sizes.  These are the
+# shapes that take the wide paths: two m-blocks / MT = 4 accumulators, 16 channels per deformable group, the two-pass
+# (Co > 64) DCN backward, 8 K-chunks per tile.
+def _conv128(seed=13):
+    torch.manual_seed(seed)
+    c = nn.Conv2d(128, 128, 3, 1, 1)
+    with torch.no_grad():
+        c.weight.mul_(0.5)
+    return c.to(dev())
+
+
+def test_config3_conv_equivariance_linearity_and_wgrad_additivity(gemm_mode):
+    from realvsr_amd import functional as RF
+    conv = _conv128()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(112, 128, 180, 320, generator=g).to(dev())
+    xs = torch.zeros_like(x)
+    xs[:, :, 3:, 5:] = x[:, :, :-3, :-5]
+    with torch.no_grad():
+        y, ys = RF.conv2d(x, conv, RF.ACT_LRELU), RF.conv2d(xs, conv, RF.ACT_LRELU)
+    assert torch.equal(ys[:, :, 5:-1, 7:-1], y[:, :, 2:-4, 2:-6])          # bit-exact at every tile seam
+    del xs, ys
+    with torch.no_grad():
+        y2 = RF.conv2d(x * 2.0, conv)
+        bias = conv.bias.view(1, -1, 1, 1)
+        y1 = RF.conv2d(x, conv)
+    check('conv(2x) == 2 conv(x)', y2 - bias, 2.0 * (y1 - bias), 5 * TOL[gemm_mode])
+    del y, y1, y2
+    gout = torch.randn(112, 128, 180, 320, generator=g).to(dev())
+
+    def wgrad(xx, go):
+        conv.zero_grad()
+        RF.conv2d(xx, conv, RF.ACT_LRELU).backward(go)
+        return conv.weight.grad.clone(), conv.bias.grad.clone()
+    gw, gb = wgrad(x, gout)
+    gw1, gb1 = wgrad(x[:48].contiguous(), gout[:48].contiguous())
+    gw2, gb2 = wgrad(x[48:].contiguous(), gout[48:].contiguous())
+    check('gW(112 frames) == gW(48) + gW(64)', gw, gw1 + gw2, 5 * TOL[gemm_mode])
+    check('gb(112 frames) == gb(48) + gb(64)', gb, gb1 + gb2, 5 * TOL[gemm_mode])
+
+
+def test_config3_dcn_zero_offsets_is_the_plain_conv_including_two_pass_backward(gemm_mode):
+    """C = Co = 128, 8 deformable groups of 16 channels, one batch-16 slice of the 112-frame alignment call, 180 x 320:
+    fused DCN forward and the Co > 64 two-pass backward (grad_input, grad_weight, grad_bias, mask-gradient identity)
+    against the independently written conv block."""
+    from realvsr_amd import functional as RF
+    from realvsr_amd.archs.dcn import modulated_deform_conv
+    conv = _conv128(seed=15)
+    g = torch.Generator().manual_seed(22)
+    B = 16
+    x = torch.randn(B, 128, 180, 320, generator=g).to(dev())
+    gout = torch.randn(B, 128, 180, 320, generator=g).to(dev())
+    off = torch.zeros(B, 8 * 18, 180, 320, device=dev(), requires_grad=True)
+    msk = torch.ones(B, 8 * 9, 180, 320, device=dev(), requires_grad=True)
+    xd = x.clone().requires_grad_(True)
+    wd, bd = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    yd = modulated_deform_conv(xd, off, msk, wd, bd, 1, 1, 1, 1, 8)
+    yd.backward(gout)
+    xc = x.clone().requires_grad_(True)
+    conv.zero_grad()
+    yc = RF.conv2d(xc, conv)
+    yc.backward(gout)
+    tol = 5 * TOL[gemm_mode]
+    check('forward', yd, yc, tol)
+    check('grad_input (two passes of 64 output channels)', xd.grad, xc.grad, tol)
+    check('grad_weight', wd.grad, conv.weight.grad, tol)
+    check('grad_bias', bd.grad, conv.bias.grad, tol)
+    lhs = float(msk.grad.double().sum())
+    rhs = float((gout.double() * (yc.detach().double() - conv.bias.detach().view(1, -1, 1, 1).double())).sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(rhs) + 1e-3, (lhs, rhs)
+    # integer offsets = shifted sampling: offset (dy, dx) = (2, -3) on every tap of every group equals the plain conv of
+    # the input shifted by (-2, +3), away from the border (there the conv pads with zeros where the sampler still
+    # reads real pixels of the unshifted image)
+    with torch.no_grad():
+        off2 = torch.zeros_like(off)
+        off2[:, 0::2] = 2.0
+        off2[:, 1::2] = -3.0
+        ysh = modulated_deform_conv(x, off2, msk.detach(), wd.detach(), bd.detach(), 1, 1, 1, 1, 8)
+        xsh = torch.zeros_like(x)
+        xsh[:, :, :-2, 3:] = x[:, :, 2:, :-3]
+        yref = RF.conv2d(xsh, conv)
+    check('integer offsets == conv of the shifted input', ysh[:, :, 3:-3, 4:-4], yref[:, :, 3:-3, 4:-4], tol)
+
+
+def test_config5_forward_properties_and_graph_runner():
+    """540 x 960 LR, nf128, 7 frames (BASELINE config 5), forward only:
+      * the nf128 conv block is bit-exactly translation-equivariant at this frame size (7 frames, every tile seam);
+      * SlidingWindowRunner(use_graph=True) on a 7-frame 540 x 960 clip: every output frame equals the plain
+        single-window forward of the net on that frame's window (bit for bit), output 2160 x 3840."""
+    from realvsr_amd import functional as RF
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    from realvsr_amd.infer import SlidingWindowRunner, index_generation
+    from weights import fill_state_dict
+    conv = _conv128(seed=17)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(7, 128, 540, 960, generator=g).to(dev())
+    xs = torch.zeros_like(x)
+    xs[:, :, 3:, 5:] = x[:, :, :-3, :-5]
+    with torch.no_grad():
+        y, ys = RF.conv2d(x, conv, RF.ACT_LRELU), RF.conv2d(xs, conv, RF.ACT_LRELU)
+    assert torch.equal(ys[:, :, 5:-1, 7:-1], y[:, :, 2:-4, 2:-6])
+    del x, xs, y, ys
+    net = EDVR(nf=128, nc=3, nframes=7, groups=8, front_RBs=5, back_RBs=2, w_TSA=True)   # back_RBs 2: test time only
+    fill_state_dict(net, 303, offset_std=0.03)
+    net = net.to(dev()).eval()
+    clip = torch.rand(7, 3, 540, 960, generator=g).to(dev())
+    run = SlidingWindowRunner(net, 7, padding='reflection', chunk=1, use_graph=True)
+    out = run(clip)
+    assert out.shape == (7, 3, 2160, 3840) and torch.isfinite(out).all()
+    with torch.no_grad():
+        for t in (0, 3, 6):            # first / centre / last frame: padded and unpadded windows
+            idx = index_generation(t, 7, 7, padding='reflection')
+            ref = net(clip[idx].unsqueeze(0))[0]
+            assert torch.equal(out[t], ref), t
