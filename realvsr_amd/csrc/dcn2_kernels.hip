@@ -1301,6 +1301,8 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     DSTAMP(130);
 }
 
+#include "dcn_bwdin4.inc"
+
 static int nk_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : 4); }  // per pass of <= 64 output channels
 size_t rvsr_dcn_bwdin3_workspace_bytes(int Co, int C) { return (size_t)((C + 7) / 8) * 3 * 2 * (2 * nk_of(Co)) * 32 * 16; }
 
@@ -1313,7 +1315,8 @@ static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* wo
                        (bf16x8*)workspace, p.o_base, p.o_cnt, d.C, nchunks);
     constexpr int TR = D3_TH + D3_PR - 1, PPOS = D3_PR * D3_TC;
     const size_t lds = (size_t)16 * (2 * TR * D3_TC + D3_TH * 2 * PPOS + 3 * 2 * (2 * NK) * 32) + (size_t)4 * D3_TH * 2 * PPOS;
-    auto k = dcn_bwdin3_kernel<NK>;
+    static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 4; }();  // developer A/B switch
+    auto k = gen >= 4 ? dcn_bwdin4_kernel<NK> : dcn_bwdin3_kernel<NK>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin3: cannot reserve %zu B of LDS", lds);
     dim3 grid(d.ntx * ((d.Ho + D3_TH - 1) / D3_TH), 1, d.B);
     hipLaunchKernelGGL(k, grid, dim3(D3_TH * 64), lds, st, p, (const bf16x8*)workspace);
