@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_PROFILE = {64: 'profiles/r01_dcn_fwd_pmc.json', 128: 'profiles/r02_dcn_fwd_pmc_nf128.json'}
+PMC_PROFILE = {64: 'profiles/r02_dcn_fwd_pmc.json', 128: 'profiles/r02_dcn_fwd_pmc_nf128.json'}
 
 
 def model_opt(args, world):
@@ -355,7 +355,7 @@ def main():
                        'offset_abs_mean_px_per_dcn': {k.split('.')[-1]: round(v[0], 4) for k, v in off.items()},
                        'offset_px_requested': args.offset_px,
                        'loss_last_step': round(float(loss.item()), 6)},
-            'roofline': {'kernel': 'dcn_fwd2_kernel (+ its weight pre-pack), fused DCN forward', 'bound': 'hbm',
+            'roofline': {'kernel': 'dcn_fwd3_kernel (+ its weight pre-pack), fused DCN forward', 'bound': 'hbm',
                          'achieved': round(kbytes / (kms * 1e-3) / 1e9, 2) if kms > 0 else None,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(TH * 64, MT <= 2 ? 4 : 2) void dcn_fwd2_kernel(cons
 
 // ------------------------------------------------------------------------------------------
 static void fwd2_geom(int Co, int C, int& mt, int& nchunks, int& nmb) {
-    mt = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+    static const int wide = [] { const char* e = getenv("RVSR_DCN_MT_WIDE"); return e ? atoi(e) : 4; }();  // developer A/B switch
+    mt = Co <= 32 ? 1 : (Co <= 64 ? 2 : wide);
     nchunks = (C + 15) / 16;
     nmb = (Co + mt * 32 - 1) / (mt * 32);
 }
