@@ -265,6 +265,13 @@ int rvsr_augment_clips(const float* im1, const float* im2, float* out1, float* o
                        int W, int perm0, int perm1, int perm2, int box_mode, int y0, int y1, int x0, int x1, float v,
                        void* stream);
 
+/* The algebraic split of the PCD "concat with the repeated reference" convs (EDVR_arch.py:100-101,109,118,127: conv(cat([nbr, ref]))
+ * with ref identical for the N frames of a window): conv(cat(x, repeat(ref))) = conv_a(x) + conv_b(ref).  These two kernels are the
+ * elementwise glue: a[n][j] = act(a[n][j] + b[j]) in place (n < N repeats of `per` floats; act 0 none, 1 ReLU, 2 LeakyReLU(slope)),
+ * and its adjoint gb[j] = sum_n gout[n][j] * act'(out[n][j]) (out NULL: no activation). */
+int rvsr_bcast_add_act(float* a, const float* b, size_t per, int N, int act, float slope, void* stream);
+int rvsr_bcast_reduce_act(const float* gout, const float* out, float* gb, size_t per, int N, float gslope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

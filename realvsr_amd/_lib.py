@@ -61,6 +61,8 @@ SIGNATURES = {
     'rvsr_pyr_upsample_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
     'rvsr_pyr_upsample_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),
     'rvsr_adam_step': (c_int, [c_fp] * 4 + [c_size] + [c_float] * 6 + [c_fp]),
+    'rvsr_bcast_add_act': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_fp]),
+    'rvsr_bcast_reduce_act': (c_int, [c_fp, c_fp, c_fp, c_size, c_int, c_float, c_fp]),
     'rvsr_augment_clips': (c_int, [c_fp] * 5 + [c_size] + [c_int] * 10 + [c_float, c_fp]),
 }
 

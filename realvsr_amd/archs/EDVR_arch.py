@@ -85,27 +85,36 @@ class PCD_Align(nn.Module):
         self.cas_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
                                extra_offset_mask=True)
 
-    def forward(self, nbr_fea_l, ref_fea_l):
-        """nbr_fea_l, ref_fea_l: [L1, L2, L3], each with [B,C,H,W] features"""
+    def forward(self, nbr_fea_l, ref_fea_l, ref_repeat=None):
+        """nbr_fea_l, ref_fea_l: [L1, L2, L3], each with [B,C,H,W] features.
+        ref_repeat = N (not in the reference signature): nbr_fea_l holds the N frames of every window frame-major
+        ([N*B, C, H, W]) and ref_fea_l the B centre-frame features ONCE; the four "concat with the reference" convs then
+        run as conv_a(nbr) + conv_b(ref) (functional.conv_cat_bcast) instead of on N repeated copies of ref."""
         conv, up = RF.conv2d, RF.upsample_bilinear
+        if ref_repeat is not None:
+            def cat_ref(x, cv, level):
+                return RF.conv_cat_bcast(x, ref_fea_l[level], cv, ref_repeat, LRELU)
+        else:
+            def cat_ref(x, cv, level):
+                return conv(x, cv, LRELU, x2=ref_fea_l[level])
         # L3
-        L3_offset = conv(nbr_fea_l[2], self.L3_offset_conv1, LRELU, x2=ref_fea_l[2])
+        L3_offset = cat_ref(nbr_fea_l[2], self.L3_offset_conv1, 2)
         L3_offset = conv(L3_offset, self.L3_offset_conv2, LRELU)
         L3_fea = self.L3_dcnpack([nbr_fea_l[2], L3_offset], act=LRELU)
         # L2
-        L2_offset = conv(nbr_fea_l[1], self.L2_offset_conv1, LRELU, x2=ref_fea_l[1])
+        L2_offset = cat_ref(nbr_fea_l[1], self.L2_offset_conv1, 1)
         L2_offset = conv(L2_offset, self.L2_offset_conv2, LRELU, x2=up(L3_offset, 2, 2.0))
         L2_offset = conv(L2_offset, self.L2_offset_conv3, LRELU)
         L2_fea = self.L2_dcnpack([nbr_fea_l[1], L2_offset])
         L2_fea = conv(L2_fea, self.L2_fea_conv, LRELU, x2=up(L3_fea, 2))
         # L1
-        L1_offset = conv(nbr_fea_l[0], self.L1_offset_conv1, LRELU, x2=ref_fea_l[0])
+        L1_offset = cat_ref(nbr_fea_l[0], self.L1_offset_conv1, 0)
         L1_offset = conv(L1_offset, self.L1_offset_conv2, LRELU, x2=up(L2_offset, 2, 2.0))
         L1_offset = conv(L1_offset, self.L1_offset_conv3, LRELU)
         L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset])
         L1_fea = conv(L1_fea, self.L1_fea_conv, x2=up(L2_fea, 2))  # no activation (EDVR_arch.py:125)
         # Cascading
-        offset = conv(L1_fea, self.cas_offset_conv1, LRELU, x2=ref_fea_l[0])
+        offset = cat_ref(L1_fea, self.cas_offset_conv1, 0)
         offset = conv(offset, self.cas_offset_conv2, LRELU)
         return self.cas_dcnpack([L1_fea, offset], act=LRELU)
 
@@ -227,17 +236,12 @@ class _EDVRBase(nn.Module):
         the centre LR frame [B, C, H, W]."""
         N = len(L1_l)
         B, _, H, W = L1_l[0].shape
-        if B * H * W > 256 * 1024:
-            # large frames (BASELINE config 5: 540x960): every per-frame kernel already fills the GPU; gathering the
-            # N*B batch would only add copies (measured 101 vs 104.5 ms per frame)
-            ref_fea_l = [L1_l[self.center], L2_l[self.center], L3_l[self.center]]
-            aligned_l = [self.pcd_align([L1_l[i], L2_l[i], L3_l[i]], ref_fea_l) for i in range(N)]
-            return self._fuse_reconstruct(torch.stack(aligned_l, dim=1), aligned_l[self.center], x_center)
-        # small frames are launch-bound: one PCD call on the N*B batch (see forward()); 7.2 -> 4.8 ms per 180x320 frame
+        # one PCD call on the frame-major N*B batch (see forward()): fewer launches / tail waves for small frames (7.2 -> 4.8 ms
+        # per 180x320 frame) and, at every size, the reference-feature half of the four concat convs runs once per window
+        # instead of once per frame (functional.conv_cat_bcast)
         nbr_l = [torch.cat(list(L1_l), 0), torch.cat(list(L2_l), 0), torch.cat(list(L3_l), 0)]
-        ref_l = [L1_l[self.center].repeat(N, 1, 1, 1), L2_l[self.center].repeat(N, 1, 1, 1),
-                 L3_l[self.center].repeat(N, 1, 1, 1)]
-        aligned_nb = self.pcd_align(nbr_l, ref_l).view(N, B, -1, H, W)
+        ref_l = [L1_l[self.center], L2_l[self.center], L3_l[self.center]]
+        aligned_nb = self.pcd_align(nbr_l, ref_l, ref_repeat=N).view(N, B, -1, H, W)
         aligned_fea = aligned_nb.transpose(0, 1).contiguous()  # [B, N, C, H, W]
         return self._fuse_reconstruct(aligned_fea, aligned_nb[self.center], x_center)
 
@@ -277,8 +281,8 @@ class _EDVRBase(nn.Module):
         nbr_l = list(self.extract_features(xf))
         if hr:
             H, W = H // 4, W // 4
-        ref_l = [f.view(N, B, *f.shape[1:])[self.center].repeat(N, 1, 1, 1) for f in nbr_l]
-        aligned = self.pcd_align(nbr_l, ref_l)                       # [N*B, nf, H, W], frame-major
+        ref_l = [f.view(N, B, *f.shape[1:])[self.center] for f in nbr_l]   # centre-frame features, ONCE (contiguous block)
+        aligned = self.pcd_align(nbr_l, ref_l, ref_repeat=N)         # [N*B, nf, H, W], frame-major
         aligned_nb = aligned.view(N, B, -1, H, W)
         aligned_fea = aligned_nb.transpose(0, 1).contiguous()        # [B, N, nf, H, W] (what torch.stack(dim=1) built)
         return self._fuse_reconstruct(aligned_fea, aligned_nb[self.center], x_center)

@@ -897,8 +897,6 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         const bf16x8* ws_hi = ws_base + buf * 2 * WVEC;
         const bf16x8* ws_lo = ws_hi + WVEC;
         const bool pub = q + 1 < Q;   // stage q+1 exists: publish it into the other buffer during this stage
-        // second M tile of the m-block entirely beyond Co (Co = 216 offset/mask convs: rows 224..255): skip its MFMAs
-        const bool m1_live = MT < 2 || tile_of(q / nchunks).mb * MP + 32 < p.Co;
         bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
         auto fetch = [&](int tap, int slot) {
             const int dy = tap / KS, dx = tap % KS;
@@ -920,23 +918,17 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             const int sl = tap & 1;
             if (tap + 1 < T) fetch(tap + 1, sl ^ 1);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (m == 1 && !m1_live) continue;   // (uniform)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bh[sl][n], acc[m][n]);
-            }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (m == 1 && !m1_live) continue;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bl[sl][n], acc[m][n]);
-            }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (m == 1 && !m1_live) continue;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[sl][m], bh[sl][n], acc[m][n]);
-            }
             // ---- this wave's own staging work, a slice per tap, in the shadow of the MFMAs above (a wave's own
             // VALU/LDS instructions fill its MFMA issue gaps; another wave's barely do):
             //   taps 0-3: publish pixel / item `tap` of stage q+1 (registers loaded during stage q-1)

@@ -292,6 +292,45 @@ __global__ void augment_clips_kernel(const float* __restrict__ im1, const float*
     }
 }
 
+// ---------------------------------------------------------------- broadcast add + activation
+// out[n][j] = act(a[n][j] + b[j]) for n < N repeats of a `per`-element block (in place on a), and its adjoint w.r.t. b:
+// gb[j] = sum_n gout[n][j] * act'(out[n][j]).  Used by the algebraic split conv(cat(x, repeat(ref))) = conv_a(x) + conv_b(ref).
+__global__ void bcast_add_act_kernel(float* __restrict__ a, const float* __restrict__ b, size_t per4, int N, int act, float slope) {
+    float4* a4 = reinterpret_cast<float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    const float neg = act == 0 ? 1.f : (act == 1 ? 0.f : slope);
+    LOOP(j, per4) {
+        const float4 bb = b4[j];
+        for (int n = 0; n < N; ++n) {
+            float4 v = a4[(size_t)n * per4 + j];
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            v.x = v.x > 0.f ? v.x : v.x * neg; v.y = v.y > 0.f ? v.y : v.y * neg;
+            v.z = v.z > 0.f ? v.z : v.z * neg; v.w = v.w > 0.f ? v.w : v.w * neg;
+            a4[(size_t)n * per4 + j] = v;
+        }
+    }
+}
+__global__ void bcast_reduce_act_kernel(const float* __restrict__ gout, const float* __restrict__ out, float* __restrict__ gb,
+                                        size_t per4, int N, float gslope, int has_act) {
+    const float4* g4 = reinterpret_cast<const float4*>(gout);
+    const float4* o4 = reinterpret_cast<const float4*>(out);
+    float4* r4 = reinterpret_cast<float4*>(gb);
+    LOOP(j, per4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < N; ++n) {
+            const float4 g = g4[(size_t)n * per4 + j];
+            if (has_act) {
+                const float4 o = o4[(size_t)n * per4 + j];
+                acc.x += g.x * (o.x > 0.f ? 1.f : gslope); acc.y += g.y * (o.y > 0.f ? 1.f : gslope);
+                acc.z += g.z * (o.z > 0.f ? 1.f : gslope); acc.w += g.w * (o.w > 0.f ? 1.f : gslope);
+            } else {
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+            }
+        }
+        r4[j] = acc;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 extern "C" size_t rvsr_reduce_workspace_bytes() { return RED_BLOCKS * sizeof(double); }
 
@@ -416,4 +455,18 @@ extern "C" int rvsr_augment_clips(const float* im1, const float* im2, float* out
     hipLaunchKernelGGL(augment_clips_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, im1, im2, out1, out2, colour, frames, H,
                        W, plan);
     CHECK_LAUNCH("augment_clips");
+}
+
+extern "C" int rvsr_bcast_add_act(float* a, const float* b, size_t per, int N, int act, float slope, void* stream) {
+    if (!a || !b || N <= 0) FAIL(RVSR_ERR_BAD_ARG, "bcast_add_act: bad argument");
+    if ((per & 3) != 0 || ((((uintptr_t)a) | ((uintptr_t)b)) & 15) != 0) FAIL(RVSR_ERR_BAD_ARG, "bcast_add_act: blocks must be 16-byte aligned multiples of 4 floats");
+    hipLaunchKernelGGL(bcast_add_act_kernel, GRID_FOR(per / 4), dim3(256), 0, (hipStream_t)stream, a, b, per / 4, N, act, slope);
+    CHECK_LAUNCH("bcast_add_act");
+}
+extern "C" int rvsr_bcast_reduce_act(const float* gout, const float* out, float* gb, size_t per, int N, float gslope, void* stream) {
+    if (!gout || !gb || N <= 0) FAIL(RVSR_ERR_BAD_ARG, "bcast_reduce_act: bad argument");
+    if ((per & 3) != 0 || ((((uintptr_t)gout) | ((uintptr_t)out) | ((uintptr_t)gb)) & 15) != 0)
+        FAIL(RVSR_ERR_BAD_ARG, "bcast_reduce_act: blocks must be 16-byte aligned multiples of 4 floats");
+    hipLaunchKernelGGL(bcast_reduce_act_kernel, GRID_FOR(per / 4), dim3(256), 0, (hipStream_t)stream, gout, out, gb, per / 4, N, gslope, out != nullptr);
+    CHECK_LAUNCH("bcast_reduce_act");
 }

@@ -188,6 +188,87 @@ class _ResBlockFused(Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+class _ConvCatBcast(Function):
+    """act(conv3x3(cat([x, ref.repeat(N, 1, 1, 1)], 1), w) + b) for a frame-major x [N*B, C1, H, W] and ref [B, C2, H, W],
+    WITHOUT the repeat and without convolving the same reference N times:
+
+        conv(cat(x, repeat(ref))) = conv_a(x) + conv_b(ref),     w = [w_a | w_b] along the input channels.
+
+    PCD_Align convolves cat([nbr, ref]) four times per frame (EDVR_arch.py:100, 109, 118, 127) and the reference
+    features are those of the window's centre frame for all N frames (:297-303): conv_b runs on B frames instead of
+    N*B (fwd, dgrad and wgrad: 2.0 -> 1.2 conv-equivalents each), the 2x-wide conv reads half the channels, and the
+    N copies of ref are never materialised.  The glue is one in-place pass (add broadcast + activation) forward and
+    one reduction over N backward; act' is taken from the saved output as everywhere else."""
+
+    @staticmethod
+    def forward(ctx, x, ref, weight, bias, N, act, slope):
+        _need_cuda(x, ref, weight, bias)
+        x, ref, weight, bias = _c(x), _c(ref), _c(weight), _c(bias)
+        NB, C1, H, W = x.shape
+        B, C2 = ref.shape[0], ref.shape[1]
+        Co, Cw, k, _ = weight.shape
+        if NB != N * B or Cw != C1 + C2 or k != 3 or tuple(ref.shape[2:]) != (H, W):
+            raise RuntimeError('conv_cat_bcast: x %s, ref %s, weight %s, N %d do not fit' % (tuple(x.shape), tuple(ref.shape), tuple(weight.shape), N))
+        w_a, w_b = weight[:, :C1].contiguous(), weight[:, C1:].contiguous()
+        out = x.new_empty(NB, Co, H, W)
+        part = x.new_empty(B, Co, H, W)
+        L = _lib.lib()
+        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(max(C1, C2), 0, Co, 3), x.device)
+        _lib.check(L.rvsr_conv2d_forward(_p(x), C1, None, 0, None, 0.0, 0, H, W, _p(w_a), _p(bias), None, _p(out), Co, None,
+                                         0, NB, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast conv_a')
+        _lib.check(L.rvsr_conv2d_forward(_p(ref), C2, None, 0, None, 0.0, 0, H, W, _p(w_b), None, None, _p(part), Co, None,
+                                         0, B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast conv_b')
+        _lib.check(L.rvsr_bcast_add_act(_p(out), _p(part), part.numel(), N, act, slope, _stream()), 'bcast_add_act')
+        ctx.cfg = (N, act, slope, bias is not None)
+        ctx.save_for_backward(x, ref, w_a, w_b, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, ref, w_a, w_b, act_out = ctx.saved_tensors
+        N, act, slope, has_bias = ctx.cfg
+        gout = gout.contiguous()
+        NB, C1, H, W = x.shape
+        B, C2 = ref.shape[0], ref.shape[1]
+        Co = w_a.shape[0]
+        L = _lib.lib()
+        gslope = 0.0 if act == ACT_RELU else slope
+        gx = gref = gw = gb = None
+        # gradient of the broadcast partial: sum over the N frames of gout * act'
+        gpart = x.new_empty(B, Co, H, W)
+        _lib.check(L.rvsr_bcast_reduce_act(_p(gout), _p(act_out), _p(gpart), gpart.numel(), N, gslope, _stream()), 'bcast_reduce_act')
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1, 3), x.device)
+            _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, 0, H, W, _p(w_a), None, None, _p(gx), C1,
+                                             None, 0, NB, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                       'conv_cat_bcast dgrad_a')
+        if ctx.needs_input_grad[1]:
+            gref = torch.empty_like(ref)
+            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C2, 3), x.device)
+            _lib.check(L.rvsr_conv2d_forward(_p(gpart), Co, None, 0, None, 0.0, 0, H, W, _p(w_b), None, None, _p(gref), C2,
+                                             None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                       'conv_cat_bcast dgrad_b')
+        if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
+            gw_a, gw_b = torch.empty_like(w_a), torch.empty_like(w_b)
+            gb = w_a.new_empty(Co) if has_bias else None
+            ws = _workspace(L.rvsr_conv2d_wgrad_workspace_bytes(C1, 0, Co, NB, 3, 1, H, W), x.device)
+            _lib.check(L.rvsr_conv2d_backward_weight(_p(x), C1, None, 0, H, W, _p(gout), _p(act_out), gslope, 0, H, W, _p(gw_a),
+                                                     _p(gb), Co, NB, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()),
+                       'conv_cat_bcast wgrad_a')
+            ws = _workspace(L.rvsr_conv2d_wgrad_workspace_bytes(C2, 0, Co, B, 3, 1, H, W), x.device)
+            _lib.check(L.rvsr_conv2d_backward_weight(_p(ref), C2, None, 0, H, W, _p(gpart), None, 0.0, 0, H, W, _p(gw_b), None,
+                                                     Co, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast wgrad_b')
+            gw = torch.cat([gw_a, gw_b], 1)
+        return gx, gref, gw, gb, None, None, None
+
+
+def conv_cat_bcast(x, ref, conv, N, act=ACT_NONE, slope=0.1):
+    """act(conv(cat([x, ref.repeat(N, 1, 1, 1)], 1))) for frame-major x [N*B, ...] and ref [B, ...] (3x3, stride 1)."""
+    return _ConvCatBcast.apply(x, ref, conv.weight, conv.bias, int(N), act, float(slope))
+
+
 def res_block(x, conv1, conv2):
     """x + conv2(relu(conv1(x))) with the identity add fused in both directions."""
     return _ResBlockFused.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
