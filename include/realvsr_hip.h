@@ -157,13 +157,14 @@ int rvsr_maxavgpool_backward(const float* gout, const unsigned char* argmax, flo
                              int W, void* stream);
 
 /* TSA temporal attention (EDVR_arch.py:171-181): prob[b,n] = sigmoid(sum_c emb[b,n,c]*emb_ref[b,c]);
- * mod[b,n,c] = aligned[b,n,c] * prob[b,n].  emb/aligned/mod (B,N,C,H,W), emb_ref (B,C,H,W),
- * prob (B,N,H,W). */
+ * mod[b,n,c] = aligned[b,n,c] * prob[b,n].  mod (B,N,C,H,W), emb_ref (B,C,H,W), prob (B,N,H,W);
+ * emb / aligned (and galigned / gemb): (B,N,C,H,W) as the reference stacks them (frame_major 0), or (N,B,C,H,W) =
+ * the frame-major batch the alignment stage works on (frame_major 1: no transposing copy between the two stages). */
 int rvsr_tsa_temporal_forward(const float* emb, const float* emb_ref, const float* aligned, float* mod,
-                              float* prob, int B, int N, int C, int H, int W, void* stream);
+                              float* prob, int B, int N, int C, int H, int W, int frame_major, void* stream);
 int rvsr_tsa_temporal_backward(const float* gmod, const float* emb, const float* emb_ref, const float* aligned,
                                const float* prob, float* galigned, float* gemb, float* gemb_ref, int B, int N,
-                               int C, int H, int W, void* stream);
+                               int C, int H, int W, int frame_major, void* stream);
 
 /* out = fea * sigmoid(att) * 2 + att_add (EDVR_arch.py:204-207); grad w.r.t. att_add is g itself. */
 int rvsr_tsa_output_forward(const float* fea, const float* att, const float* att_add, float* out, size_t n,

@@ -37,8 +37,8 @@ SIGNATURES = {
     'rvsr_upsample_bilinear_backward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_int, c_float, c_fp]),
     'rvsr_maxavgpool_forward': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     'rvsr_maxavgpool_backward': (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
-    'rvsr_tsa_temporal_forward': (c_int, [c_fp] * 5 + [c_int] * 5 + [c_fp]),
-    'rvsr_tsa_temporal_backward': (c_int, [c_fp] * 8 + [c_int] * 5 + [c_fp]),
+    'rvsr_tsa_temporal_forward': (c_int, [c_fp] * 5 + [c_int] * 6 + [c_fp]),
+    'rvsr_tsa_temporal_backward': (c_int, [c_fp] * 8 + [c_int] * 6 + [c_fp]),
     'rvsr_tsa_output_forward': (c_int, [c_fp] * 4 + [c_size, c_fp]),
     'rvsr_tsa_output_backward': (c_int, [c_fp] * 5 + [c_size, c_fp]),
     'rvsr_pyr_down_forward': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_fp]),

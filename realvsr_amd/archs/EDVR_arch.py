@@ -7,8 +7,8 @@ is the fused HIP operators of realvsr_amd.functional:
     two pointers, ``F.interpolate(...) * 2`` is one kernel, PixelShuffle is folded into the conv;
   * each DCN pack = one conv kernel + one fused DCN kernel (LeakyReLU in its epilogue);
   * TSA's correlation / sigmoid / modulation and its output gate are one kernel each.
-The optional ``predeblur`` / ``HR_in`` branches (EDVR_arch.py:224-231,264-274) are enabled by no
-shipped config and are not built: requesting them raises.
+The optional ``predeblur`` / ``HR_in`` front ends (EDVR_arch.py:224-231,264-274; enabled by no shipped config) are
+built on the same operators (Predeblur_ResNet_Pyramid below) and pinned by tests/golden/edvr_predeblur.npz.
 """
 import functools
 
@@ -56,31 +56,28 @@ class Predeblur_ResNet_Pyramid(nn.Module):
 
 
 class PCD_Align(nn.Module):
-    """Alignment module using Pyramid, Cascading and Deformable convolution, 3 pyramid levels."""
+    """PCD alignment (EDVR_arch.py:62-132): offsets predicted coarse-to-fine on a 3-level feature pyramid (L3 -> L2 -> L1), one
+    modulated DCN per level plus a cascading one; parameter names = the reference's (state_dict schema)."""
 
     def __init__(self, nf=64, groups=8):
         super(PCD_Align, self).__init__()
-        # L3: level 3, 1/4 spatial size
-        self.L3_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
+        self.L3_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
         self.L3_offset_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
         self.L3_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
                               extra_offset_mask=True)
-        # L2: level 2, 1/2 spatial size
-        self.L2_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
-        self.L2_offset_conv2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for offset
+        self.L2_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
+        self.L2_offset_conv2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
         self.L2_offset_conv3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
         self.L2_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
                               extra_offset_mask=True)
-        self.L2_fea_conv = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for fea
-        # L1: level 1, original spatial size
-        self.L1_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
-        self.L1_offset_conv2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for offset
+        self.L2_fea_conv = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
+        self.L1_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
+        self.L1_offset_conv2 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
         self.L1_offset_conv3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
         self.L1_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
                               extra_offset_mask=True)
-        self.L1_fea_conv = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for fea
-        # Cascading DCN
-        self.cas_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)  # concat for diff
+        self.L1_fea_conv = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
+        self.cas_offset_conv1 = nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=True)
         self.cas_offset_conv2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
         self.cas_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
                                extra_offset_mask=True)
@@ -97,40 +94,34 @@ class PCD_Align(nn.Module):
         else:
             def cat_ref(x, cv, level):
                 return conv(x, cv, LRELU, x2=ref_fea_l[level])
-        # L3
         L3_offset = cat_ref(nbr_fea_l[2], self.L3_offset_conv1, 2)
         L3_offset = conv(L3_offset, self.L3_offset_conv2, LRELU)
         L3_fea = self.L3_dcnpack([nbr_fea_l[2], L3_offset], act=LRELU)
-        # L2
         L2_offset = cat_ref(nbr_fea_l[1], self.L2_offset_conv1, 1)
         L2_offset = conv(L2_offset, self.L2_offset_conv2, LRELU, x2=up(L3_offset, 2, 2.0))
         L2_offset = conv(L2_offset, self.L2_offset_conv3, LRELU)
         L2_fea = self.L2_dcnpack([nbr_fea_l[1], L2_offset])
         L2_fea = conv(L2_fea, self.L2_fea_conv, LRELU, x2=up(L3_fea, 2))
-        # L1
         L1_offset = cat_ref(nbr_fea_l[0], self.L1_offset_conv1, 0)
         L1_offset = conv(L1_offset, self.L1_offset_conv2, LRELU, x2=up(L2_offset, 2, 2.0))
         L1_offset = conv(L1_offset, self.L1_offset_conv3, LRELU)
         L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset])
         L1_fea = conv(L1_fea, self.L1_fea_conv, x2=up(L2_fea, 2))  # no activation (EDVR_arch.py:125)
-        # Cascading
         offset = cat_ref(L1_fea, self.cas_offset_conv1, 0)
         offset = conv(offset, self.cas_offset_conv2, LRELU)
         return self.cas_dcnpack([L1_fea, offset], act=LRELU)
 
 
 class TSA_Fusion(nn.Module):
-    """Temporal Spatial Attention fusion module. Temporal: correlation; Spatial: 3 pyramid levels."""
+    """TSA fusion (EDVR_arch.py:135-208): per-frame correlation with the centre frame gates the aligned features, a 1x1 conv
+    fuses them, a 3-level max/avg-pool pyramid produces the spatial gate; parameter names = the reference's."""
 
     def __init__(self, nf=64, nframes=5, center=2):
         super(TSA_Fusion, self).__init__()
         self.center = center
-        # temporal attention (before fusion conv)
         self.tAtt_1 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
         self.tAtt_2 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
-        # fusion conv: using 1x1 to save parameters and computation
         self.fea_fusion = nn.Conv2d(nframes * nf, nf, 1, 1, bias=True)
-        # spatial attention (after fusion conv)
         self.sAtt_1 = nn.Conv2d(nframes * nf, nf, 1, 1, bias=True)
         self.sAtt_2 = nn.Conv2d(nf * 2, nf, 1, 1, bias=True)
         self.sAtt_3 = nn.Conv2d(nf, nf, 3, 1, 1, bias=True)
@@ -142,23 +133,23 @@ class TSA_Fusion(nn.Module):
         self.sAtt_add_1 = nn.Conv2d(nf, nf, 1, 1, bias=True)
         self.sAtt_add_2 = nn.Conv2d(nf, nf, 1, 1, bias=True)
 
-    def forward(self, aligned_fea, center_fea=None):
-        """aligned_fea: [B, N, C, H, W].  center_fea (optional, not in the reference signature): the tensor that was
-        stacked at index `center`; passing it avoids slicing the stack (a strided copy forward and a full-size
-        zero-fill + add in autograd's select backward)."""
+    def forward(self, aligned_fea, center_fea=None, frame_major=False):
+        """aligned_fea: [B, N, C, H, W] (reference signature).  Two optional extensions used by EDVR.forward:
+        center_fea -- the tensor that was stacked at index `center` (avoids slicing the stack);
+        frame_major -- aligned_fea is [N, B, C, H, W], the frame-major batch of the alignment stage as it is: the
+        temporal-attention front then runs as one fused autograd node (functional.tsa_temporal_block), no transposing copy."""
         conv, up = RF.conv2d, RF.upsample_bilinear
-        B, N, C, H, W = aligned_fea.size()  # N video frames
-        aligned_fea = aligned_fea.contiguous()
-        #### temporal attention
-        emb_ref = conv(aligned_fea[:, self.center] if center_fea is None else center_fea, self.tAtt_2)
-        emb = conv(aligned_fea.view(-1, C, H, W), self.tAtt_1).view(B, N, -1, H, W)
-        aligned_fea = RF.tsa_temporal(emb, emb_ref, aligned_fea)  # [B, N*C, H, W]
-        #### fusion
+        if frame_major:
+            aligned_fea = RF.tsa_temporal_block(aligned_fea, self.center, self.tAtt_1, self.tAtt_2)  # [B, N*C, H, W]
+        else:
+            B, N, C, H, W = aligned_fea.size()  # N video frames
+            aligned_fea = aligned_fea.contiguous()
+            emb_ref = conv(aligned_fea[:, self.center] if center_fea is None else center_fea, self.tAtt_2)
+            emb = conv(aligned_fea.view(-1, C, H, W), self.tAtt_1).view(B, N, -1, H, W)
+            aligned_fea = RF.tsa_temporal(emb, emb_ref, aligned_fea)  # [B, N*C, H, W]
         fea = conv(aligned_fea, self.fea_fusion, LRELU)
-        #### spatial attention
         att = conv(aligned_fea, self.sAtt_1, LRELU)
         att = conv(RF.maxavgpool(att), self.sAtt_2, LRELU)
-        # pyramid levels
         att_L = conv(att, self.sAtt_L1, LRELU)
         att_L = conv(RF.maxavgpool(att_L), self.sAtt_L2, LRELU)
         att_L = up(conv(att_L, self.sAtt_L3, LRELU), 2)
@@ -183,7 +174,6 @@ class _EDVRBase(nn.Module):
         self.HR_in = True if HR_in else False
         self.w_TSA = w_TSA
         ResidualBlock_noBN_f = functools.partial(arch_util.ResidualBlock_noBN, nf=nf)
-        #### extract features (for each frame)
         if self.upscale and self.is_predeblur:
             self.pre_deblur = Predeblur_ResNet_Pyramid(nf=nf, HR_in=self.HR_in)
             self.conv_1x1 = nn.Conv2d(nf, nf, 1, 1, bias=True)
@@ -203,7 +193,6 @@ class _EDVRBase(nn.Module):
             self.tsa_fusion = TSA_Fusion(nf=nf, nframes=nframes, center=self.center)
         else:
             self.tsa_fusion = nn.Conv2d(nframes * nf, nf, 1, 1, bias=True)
-        #### reconstruction
         self.recon_trunk = arch_util.make_layer(ResidualBlock_noBN_f, back_RBs)
         if self.upscale:
             self.upconv1 = nn.Conv2d(nf, nf * 4, 3, 1, 1, bias=True)
@@ -242,17 +231,16 @@ class _EDVRBase(nn.Module):
         nbr_l = [torch.cat(list(L1_l), 0), torch.cat(list(L2_l), 0), torch.cat(list(L3_l), 0)]
         ref_l = [L1_l[self.center], L2_l[self.center], L3_l[self.center]]
         aligned_nb = self.pcd_align(nbr_l, ref_l, ref_repeat=N).view(N, B, -1, H, W)
-        aligned_fea = aligned_nb.transpose(0, 1).contiguous()  # [B, N, C, H, W]
-        return self._fuse_reconstruct(aligned_fea, aligned_nb[self.center], x_center)
+        return self._fuse_reconstruct(aligned_nb, x_center)
 
-    def _fuse_reconstruct(self, aligned_fea, center_fea, x_center):
-        """TSA fusion (or the 1x1 fusion conv) + reconstruction on aligned features [B, N, C, H, W]."""
+    def _fuse_reconstruct(self, aligned_nb, x_center):
+        """TSA fusion (or the 1x1 fusion conv) + reconstruction on the frame-major aligned features [N, B, C, H, W]."""
         conv = RF.conv2d
-        B, N, _, H, W = aligned_fea.shape
+        N, B, _, H, W = aligned_nb.shape
         if self.w_TSA:
-            fea = self.tsa_fusion(aligned_fea, center_fea=center_fea)
-        else:
-            fea = conv(aligned_fea.reshape(B, -1, H, W), self.tsa_fusion)
+            fea = self.tsa_fusion(aligned_nb, frame_major=True)
+        else:   # what torch.stack(dim=1).view(B, -1, H, W) built (EDVR_arch.py:305-308)
+            fea = conv(aligned_nb.transpose(0, 1).reshape(B, -1, H, W), self.tsa_fusion)
         out = self.recon_trunk(fea)
         if self.upscale:
             out = conv(out, self.upconv1, LRELU, pixel_shuffle=True)
@@ -283,9 +271,7 @@ class _EDVRBase(nn.Module):
             H, W = H // 4, W // 4
         ref_l = [f.view(N, B, *f.shape[1:])[self.center] for f in nbr_l]   # centre-frame features, ONCE (contiguous block)
         aligned = self.pcd_align(nbr_l, ref_l, ref_repeat=N)         # [N*B, nf, H, W], frame-major
-        aligned_nb = aligned.view(N, B, -1, H, W)
-        aligned_fea = aligned_nb.transpose(0, 1).contiguous()        # [B, N, nf, H, W] (what torch.stack(dim=1) built)
-        return self._fuse_reconstruct(aligned_fea, aligned_nb[self.center], x_center)
+        return self._fuse_reconstruct(aligned.view(N, B, -1, H, W), x_center)
 
 
 class EDVR(_EDVRBase):

@@ -142,19 +142,21 @@ __global__ void pool_bwd_kernel(const float* __restrict__ gout, const unsigned c
 // ---------------------------------------------------------------- TSA temporal attention
 __global__ void tsa_corr_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ emb_ref,
                                     const float* __restrict__ aligned, float* __restrict__ mod,
-                                    float* __restrict__ prob, int B, int N, int C, size_t HW) {
+                                    float* __restrict__ prob, int B, int N, int C, size_t HW, int frame_major) {
     const size_t n = (size_t)B * N * HW;
     LOOP(i, n) {
         const size_t px = i % HW;
         const int f = (int)((i / HW) % N);
         const int b = (int)(i / (HW * N));
-        const float* e = emb + (((size_t)b * N + f) * C) * HW + px;
+        // emb / aligned: [B][N] (the reference's stack(dim=1)) or frame-major [N][B] (the PCD batch as it is); mod / prob: [B][N]
+        const size_t fb = frame_major ? (size_t)f * B + b : (size_t)b * N + f;
+        const float* e = emb + (fb * C) * HW + px;
         const float* r = emb_ref + ((size_t)b * C) * HW + px;
         float cor = 0.f;
         for (int c = 0; c < C; ++c) cor += e[(size_t)c * HW] * r[(size_t)c * HW];
         const float pr = 1.f / (1.f + __expf(-cor));
         prob[i] = pr;
-        const float* a = aligned + (((size_t)b * N + f) * C) * HW + px;
+        const float* a = aligned + (fb * C) * HW + px;
         float* m = mod + (((size_t)b * N + f) * C) * HW + px;
         for (int c = 0; c < C; ++c) m[(size_t)c * HW] = a[(size_t)c * HW] * pr;
     }
@@ -165,20 +167,21 @@ __global__ void tsa_corr_bwd_kernel(const float* __restrict__ gmod, const float*
                                     const float* __restrict__ emb_ref, const float* __restrict__ aligned,
                                     const float* __restrict__ prob, float* __restrict__ galigned,
                                     float* __restrict__ gemb, float* __restrict__ gemb_ref, int B, int N, int C,
-                                    size_t HW) {
+                                    size_t HW, int frame_major) {
     const size_t n = (size_t)B * HW;
     LOOP(i, n) {
         const size_t px = i % HW;
         const int b = (int)(i / HW);
         float gcor[TSA_MAXN];
         for (int f = 0; f < N; ++f) {
-            const size_t base = (((size_t)b * N + f) * C) * HW + px;
+            const size_t base = (((size_t)b * N + f) * C) * HW + px;                                      // gmod: [B][N]
+            const size_t bin = ((frame_major ? (size_t)f * B + b : (size_t)b * N + f) * C) * HW + px;     // aligned / galigned
             const float pr = prob[((size_t)b * N + f) * HW + px];
             float gp = 0.f;
             for (int c = 0; c < C; ++c) {
                 const float g = gmod[base + (size_t)c * HW];
-                gp += g * aligned[base + (size_t)c * HW];
-                galigned[base + (size_t)c * HW] = g * pr;
+                gp += g * aligned[bin + (size_t)c * HW];
+                galigned[bin + (size_t)c * HW] = g * pr;
             }
             gcor[f] = gp * pr * (1.f - pr);
         }
@@ -187,7 +190,7 @@ __global__ void tsa_corr_bwd_kernel(const float* __restrict__ gmod, const float*
             const float rv = r[(size_t)c * HW];
             float s = 0.f;
             for (int f = 0; f < N; ++f) {
-                const size_t idx = (((size_t)b * N + f) * C + c) * HW + px;
+                const size_t idx = ((frame_major ? (size_t)f * B + b : (size_t)b * N + f) * C + c) * HW + px;
                 s += gcor[f] * emb[idx];
                 gemb[idx] = gcor[f] * rv;
             }
@@ -417,22 +420,22 @@ extern "C" int rvsr_maxavgpool_backward(const float* gout, const unsigned char* 
     CHECK_LAUNCH("pool_bwd");
 }
 extern "C" int rvsr_tsa_temporal_forward(const float* emb, const float* emb_ref, const float* aligned, float* mod,
-                                         float* prob, int B, int N, int C, int H, int W, void* stream) {
+                                         float* prob, int B, int N, int C, int H, int W, int frame_major, void* stream) {
     if (!emb || !emb_ref || !aligned || !mod || !prob) FAIL(RVSR_ERR_BAD_ARG, "tsa_temporal: null argument");
     const size_t n = (size_t)B * N * H * W;
     hipLaunchKernelGGL(tsa_corr_fwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, emb, emb_ref, aligned, mod, prob, B, N,
-                       C, (size_t)H * W);
+                       C, (size_t)H * W, frame_major);
     CHECK_LAUNCH("tsa_corr_fwd");
 }
 extern "C" int rvsr_tsa_temporal_backward(const float* gmod, const float* emb, const float* emb_ref, const float* aligned,
                                           const float* prob, float* galigned, float* gemb, float* gemb_ref, int B, int N,
-                                          int C, int H, int W, void* stream) {
+                                          int C, int H, int W, int frame_major, void* stream) {
     if (!gmod || !emb || !emb_ref || !aligned || !prob || !galigned || !gemb || !gemb_ref)
         FAIL(RVSR_ERR_BAD_ARG, "tsa_temporal backward: null argument");
     if (N > TSA_MAXN) FAIL(RVSR_ERR_UNSUPPORTED, "tsa_temporal backward: nframes %d > %d", N, TSA_MAXN);
     const size_t n = (size_t)B * H * W;
     hipLaunchKernelGGL(tsa_corr_bwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, gmod, emb, emb_ref, aligned, prob,
-                       galigned, gemb, gemb_ref, B, N, C, (size_t)H * W);
+                       galigned, gemb, gemb_ref, B, N, C, (size_t)H * W, frame_major);
     CHECK_LAUNCH("tsa_corr_bwd");
 }
 extern "C" int rvsr_tsa_output_forward(const float* fea, const float* att, const float* att_add, float* out, size_t n,

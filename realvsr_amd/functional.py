@@ -468,7 +468,7 @@ class _TSATemporal(Function):
         mod = aligned.new_empty(B, N * C, H, W)
         prob = aligned.new_empty(B, N, H, W)
         _lib.check(_lib.lib().rvsr_tsa_temporal_forward(_p(emb), _p(emb_ref), _p(aligned), _p(mod), _p(prob), B, N, C,
-                                                        H, W, _stream()), 'tsa_temporal_forward')
+                                                        H, W, 0, _stream()), 'tsa_temporal_forward')
         ctx.save_for_backward(emb, emb_ref, aligned, prob)
         return mod
 
@@ -480,7 +480,7 @@ class _TSATemporal(Function):
         gmod = gmod.contiguous()
         galigned, gemb, gemb_ref = torch.empty_like(aligned), torch.empty_like(emb), torch.empty_like(emb_ref)
         _lib.check(_lib.lib().rvsr_tsa_temporal_backward(_p(gmod), _p(emb), _p(emb_ref), _p(aligned), _p(prob),
-                                                         _p(galigned), _p(gemb), _p(gemb_ref), B, N, C, H, W,
+                                                         _p(galigned), _p(gemb), _p(gemb_ref), B, N, C, H, W, 0,
                                                          _stream()), 'tsa_temporal_backward')
         return gemb, gemb_ref, galigned
 
@@ -488,6 +488,85 @@ class _TSATemporal(Function):
 def tsa_temporal(emb, emb_ref, aligned):
     """aligned * sigmoid(sum_c emb * emb_ref), returned as (B, N*C, H, W)"""
     return _TSATemporal.apply(emb, emb_ref, aligned)
+
+
+class _TSATemporalBlock(Function):
+    """The temporal-attention front of TSA_Fusion (EDVR_arch.py:171-181) as ONE autograd node on the frame-major batch the
+    alignment stage produces: emb = tAtt_1(aligned), emb_ref = tAtt_2(aligned[center]), mod[b, n*C + c] =
+    aligned[n, b, c] * sigmoid(<emb[n, b], emb_ref[b]>).  `aligned` is [N, B, C, H, W]; no stack / transposing copy.
+    Backward writes the gradient of `aligned` exactly once: the modulation gradient, then tAtt_1's data gradient with that
+    buffer as its fused residual, then tAtt_2's into the centre block (three full-size autograd adds, a zero fill and two
+    590 MB transposes per step at config 2 otherwise)."""
+
+    @staticmethod
+    def forward(ctx, aligned, center, w1, b1, w2, b2):
+        _need_cuda(aligned, w1, b1, w2, b2)
+        aligned, w1, b1, w2, b2 = _c(aligned), _c(w1), _c(b1), _c(w2), _c(b2)
+        N, B, C, H, W = aligned.shape
+        if tuple(w1.shape) != (C, C, 3, 3) or tuple(w2.shape) != (C, C, 3, 3):
+            raise RuntimeError('tsa_temporal_block: expected two %dx%dx3x3 convs' % (C, C))
+        L = _lib.lib()
+        emb = aligned.new_empty(N, B, C, H, W)
+        emb_ref = aligned.new_empty(B, C, H, W)
+        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), aligned.device)
+        cen = aligned[center]
+        _lib.check(L.rvsr_conv2d_forward(_p(aligned), C, None, 0, None, 0.0, 0, H, W, _p(w1), _p(b1), None, _p(emb), C, None, 0,
+                                         N * B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'tsa tAtt_1')
+        _lib.check(L.rvsr_conv2d_forward(_p(cen), C, None, 0, None, 0.0, 0, H, W, _p(w2), _p(b2), None, _p(emb_ref), C, None, 0,
+                                         B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'tsa tAtt_2')
+        mod = aligned.new_empty(B, N * C, H, W)
+        prob = aligned.new_empty(B, N, H, W)
+        _lib.check(L.rvsr_tsa_temporal_forward(_p(emb), _p(emb_ref), _p(aligned), _p(mod), _p(prob), B, N, C, H, W, 1, _stream()),
+                   'tsa_temporal_forward')
+        ctx.center = center
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.save_for_backward(aligned, emb, emb_ref, prob, w1, w2)
+        return mod
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gmod):
+        aligned, emb, emb_ref, prob, w1, w2 = ctx.saved_tensors
+        N, B, C, H, W = aligned.shape
+        center = ctx.center
+        gmod = gmod.contiguous()
+        L = _lib.lib()
+        galigned, gemb, gemb_ref = torch.empty_like(aligned), torch.empty_like(emb), torch.empty_like(emb_ref)
+        _lib.check(L.rvsr_tsa_temporal_backward(_p(gmod), _p(emb), _p(emb_ref), _p(aligned), _p(prob), _p(galigned), _p(gemb),
+                                                _p(gemb_ref), B, N, C, H, W, 1, _stream()), 'tsa_temporal_backward')
+        gw1 = gb1 = gw2 = gb2 = None
+        cen = aligned[center]
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            gw1 = torch.empty_like(w1)
+            gb1 = w1.new_empty(C) if ctx.has_bias[0] else None
+            ws = _workspace(L.rvsr_conv2d_wgrad_workspace_bytes(C, 0, C, N * B, 3, 1, H, W), aligned.device)
+            _lib.check(L.rvsr_conv2d_backward_weight(_p(aligned), C, None, 0, H, W, _p(gemb), None, 0.0, 0, H, W, _p(gw1), _p(gb1),
+                                                     C, N * B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'tsa wgrad tAtt_1')
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            gw2 = torch.empty_like(w2)
+            gb2 = w2.new_empty(C) if ctx.has_bias[1] else None
+            ws = _workspace(L.rvsr_conv2d_wgrad_workspace_bytes(C, 0, C, B, 3, 1, H, W), aligned.device)
+            _lib.check(L.rvsr_conv2d_backward_weight(_p(cen), C, None, 0, H, W, _p(gemb_ref), None, 0.0, 0, H, W, _p(gw2), _p(gb2),
+                                                     C, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'tsa wgrad tAtt_2')
+        if ctx.needs_input_grad[0]:
+            # galigned += dgrad(tAtt_1)(gemb), in place: the kernel's fused residual is its own output buffer (every lane reads
+            # the residual values of exactly the addresses it then stores)
+            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), aligned.device)
+            _lib.check(L.rvsr_conv2d_forward(_p(gemb), C, None, 0, None, 0.0, 0, H, W, _p(w1), None, _p(galigned), _p(galigned), C,
+                                             None, 0, N * B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                       'tsa dgrad tAtt_1')
+            gcen = galigned[center]
+            _lib.check(L.rvsr_conv2d_forward(_p(gemb_ref), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, _p(gcen), _p(gcen), C,
+                                             None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                       'tsa dgrad tAtt_2')
+        else:
+            galigned = None
+        return galigned, None, gw1, gb1, gw2, gb2
+
+
+def tsa_temporal_block(aligned_nb, center, tAtt_1, tAtt_2):
+    """aligned_nb: [N, B, C, H, W] frame-major -> modulated features [B, N*C, H, W]"""
+    return _TSATemporalBlock.apply(aligned_nb, int(center), tAtt_1.weight, tAtt_1.bias, tAtt_2.weight, tAtt_2.bias)
 
 
 class _TSAOutput(Function):
