@@ -944,6 +944,8 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdw3_kernel(const DcnBwdW2Params 
     }
 }
 
+#include "dcn_bwdw4.inc"
+
 // returns the number of partials written (8 * P), or -1 if the geometry is not covered
 int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* bpart_or_null, int P, int nty, int gy, int gz,
                           hipStream_t st) {
@@ -954,6 +956,12 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
     constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
     if (rvsr_g_gemm_mode == 0) {  // bf16x3
         const size_t lds3 = (size_t)16 * 2 * TR * TC + (size_t)2 * (64 + 96) * 272;
+        static const int gen = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 4; }();  // developer A/B switch
+        if (gen >= 4 && d.stride == 1 && d.dil == 1 && g.mode == 0 && (d.Wo & 3) == 0 && p.gvec) {
+            if (set_lds(dcn_bwdw4_kernel, lds3)) return -2;
+            hipLaunchKernelGGL(dcn_bwdw4_kernel, dim3(P, gy, gz), dim3(512), lds3, st, p);
+            return 8 * P;
+        }
         if (set_lds(dcn_bwdw3_kernel, lds3)) return -2;
         hipLaunchKernelGGL(dcn_bwdw3_kernel, dim3(P, gy, gz), dim3(512), lds3, st, p);
         return 8 * P;
