@@ -11,6 +11,7 @@ The optional ``predeblur`` / ``HR_in`` front ends (EDVR_arch.py:224-231,264-274;
 built on the same operators (Predeblur_ResNet_Pyramid below) and pinned by tests/golden/edvr_predeblur.npz.
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -20,6 +21,7 @@ from .dcn import ModulatedDeformConvPack as DCN
 from .. import functional as RF
 
 LRELU = RF.ACT_LRELU
+_USE_SINKS = os.environ.get('RVSR_GRAD_SINKS', '1') != '0'   # developer A/B switch (functional.GradSink)
 
 
 class Predeblur_ResNet_Pyramid(nn.Module):
@@ -82,34 +84,44 @@ class PCD_Align(nn.Module):
         self.cas_dcnpack = DCN(nf, nf, 3, stride=1, padding=1, dilation=1, deformable_groups=groups,
                                extra_offset_mask=True)
 
-    def forward(self, nbr_fea_l, ref_fea_l, ref_repeat=None):
+    def forward(self, nbr_fea_l, ref_fea_l, ref_repeat=None, ref_block=0, sinks=None):
         """nbr_fea_l, ref_fea_l: [L1, L2, L3], each with [B,C,H,W] features.
-        ref_repeat = N (not in the reference signature): nbr_fea_l holds the N frames of every window frame-major
-        ([N*B, C, H, W]) and ref_fea_l the B centre-frame features ONCE; the four "concat with the reference" convs then
-        run as conv_a(nbr) + conv_b(ref) (functional.conv_cat_bcast) instead of on N repeated copies of ref."""
+        Extensions used by EDVR.forward (not in the reference signature):
+        ref_repeat = N -- nbr_fea_l holds the N frames of every window frame-major ([N*B, C, H, W]) and ref_fea_l the B
+          centre-frame features ONCE (block `ref_block` of nbr_fea_l); the four "concat with the reference" convs then run as
+          conv_a(nbr) + conv_b(ref) (functional.conv_cat_bcast) instead of on N repeated copies of ref;
+        sinks -- one functional.GradSink per level for nbr_fea_l: its consumers here (offset conv, DCN, reference block)
+          accumulate their gradients in one buffer instead of through autograd's adds."""
         conv, up = RF.conv2d, RF.upsample_bilinear
+        sk = sinks if (sinks is not None and ref_repeat is not None) else [None, None, None]
         if ref_repeat is not None:
-            def cat_ref(x, cv, level):
-                return RF.conv_cat_bcast(x, ref_fea_l[level], cv, ref_repeat, LRELU)
+            def cat_ref(x, cv, level, x_sink=None, x_owner=False):
+                return RF.conv_cat_bcast(x, ref_fea_l[level], cv, ref_repeat, LRELU, x_sink=x_sink, x_owner=x_owner,
+                                         ref_sink=sk[level], ref_block=ref_block)
         else:
-            def cat_ref(x, cv, level):
+            def cat_ref(x, cv, level, x_sink=None, x_owner=False):
                 return conv(x, cv, LRELU, x2=ref_fea_l[level])
-        L3_offset = cat_ref(nbr_fea_l[2], self.L3_offset_conv1, 2)
+        # level 3 (this conv is the first consumer of the L3 features: it owns their sink)
+        L3_offset = cat_ref(nbr_fea_l[2], self.L3_offset_conv1, 2, sk[2], True)
         L3_offset = conv(L3_offset, self.L3_offset_conv2, LRELU)
-        L3_fea = self.L3_dcnpack([nbr_fea_l[2], L3_offset], act=LRELU)
-        L2_offset = cat_ref(nbr_fea_l[1], self.L2_offset_conv1, 1)
+        L3_fea = self.L3_dcnpack([nbr_fea_l[2], L3_offset], act=LRELU, sink=sk[2])
+        # level 2
+        L2_offset = cat_ref(nbr_fea_l[1], self.L2_offset_conv1, 1, sk[1])
         L2_offset = conv(L2_offset, self.L2_offset_conv2, LRELU, x2=up(L3_offset, 2, 2.0))
         L2_offset = conv(L2_offset, self.L2_offset_conv3, LRELU)
-        L2_fea = self.L2_dcnpack([nbr_fea_l[1], L2_offset])
+        L2_fea = self.L2_dcnpack([nbr_fea_l[1], L2_offset], sink=sk[1])
         L2_fea = conv(L2_fea, self.L2_fea_conv, LRELU, x2=up(L3_fea, 2))
-        L1_offset = cat_ref(nbr_fea_l[0], self.L1_offset_conv1, 0)
+        # level 1
+        L1_offset = cat_ref(nbr_fea_l[0], self.L1_offset_conv1, 0, sk[0])
         L1_offset = conv(L1_offset, self.L1_offset_conv2, LRELU, x2=up(L2_offset, 2, 2.0))
         L1_offset = conv(L1_offset, self.L1_offset_conv3, LRELU)
-        L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset])
+        L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset], sink=sk[0])
         L1_fea = conv(L1_fea, self.L1_fea_conv, x2=up(L2_fea, 2))  # no activation (EDVR_arch.py:125)
-        offset = cat_ref(L1_fea, self.cas_offset_conv1, 0)
+        # cascading DCN: L1_fea feeds the offset conv (owner of its sink) and the DCN
+        cas_sink = RF.GradSink() if (ref_repeat is not None and sinks is not None) else None
+        offset = cat_ref(L1_fea, self.cas_offset_conv1, 0, cas_sink, True)
         offset = conv(offset, self.cas_offset_conv2, LRELU)
-        return self.cas_dcnpack([L1_fea, offset], act=LRELU)
+        return self.cas_dcnpack([L1_fea, offset], act=LRELU, sink=cas_sink)
 
 
 class TSA_Fusion(nn.Module):
@@ -201,7 +213,7 @@ class _EDVRBase(nn.Module):
         self.HRconv = nn.Conv2d(64, 64, 3, 1, 1, bias=True)
         self.conv_last = nn.Conv2d(64, nc, 3, 1, 1, bias=True)
 
-    def extract_features(self, frames):
+    def extract_features(self, frames, sinks=None):
         """Per-frame part of the network (EDVR_arch.py:275-289): conv_first, the front residual blocks and the
         L2/L3 pyramid convs on a [M, C, H, W] stack of frames.  It does not depend on which window a frame is in,
         which is what the sliding-window driver (realvsr_amd/infer.py) exploits."""
@@ -213,10 +225,18 @@ class _EDVRBase(nn.Module):
         else:
             L1_fea = conv(frames, self.conv_first, LRELU)
         L1_fea = self.feature_extraction(L1_fea)
-        L2_fea = conv(L1_fea, self.fea_L2_conv1, LRELU)
+        # sinks (training forward only): the stride-2 convs are the FIRST consumers of L1_fea / L2_fea, i.e. the owners of the
+        # gradient sinks their later consumers in PCD_Align deposit into (functional.GradSink)
+        if sinks is not None:
+            sinks[0].shape = tuple(L1_fea.shape)
+        L2_fea = conv(L1_fea, self.fea_L2_conv1, LRELU, sink=sinks[0] if sinks is not None else None)
         L2_fea = conv(L2_fea, self.fea_L2_conv2, LRELU)
-        L3_fea = conv(L2_fea, self.fea_L3_conv1, LRELU)
+        if sinks is not None:
+            sinks[1].shape = tuple(L2_fea.shape)
+        L3_fea = conv(L2_fea, self.fea_L3_conv1, LRELU, sink=sinks[1] if sinks is not None else None)
         L3_fea = conv(L3_fea, self.fea_L3_conv2, LRELU)
+        if sinks is not None:
+            sinks[2].shape = tuple(L3_fea.shape)
         return L1_fea, L2_fea, L3_fea
 
     def align_fuse_reconstruct(self, L1_l, L2_l, L3_l, x_center):
@@ -266,11 +286,12 @@ class _EDVRBase(nn.Module):
         # weight packs) and autograd sees no per-frame slices (each `[:, i]` costs a full-size zero fill and add in
         # select-backward).
         xf = x.transpose(0, 1).contiguous().view(N * B, C, H, W)
-        nbr_l = list(self.extract_features(xf))
+        sinks = [RF.GradSink() for _ in range(3)] if (torch.is_grad_enabled() and _USE_SINKS) else None
+        nbr_l = list(self.extract_features(xf, sinks))
         if hr:
             H, W = H // 4, W // 4
         ref_l = [f.view(N, B, *f.shape[1:])[self.center] for f in nbr_l]   # centre-frame features, ONCE (contiguous block)
-        aligned = self.pcd_align(nbr_l, ref_l, ref_repeat=N)         # [N*B, nf, H, W], frame-major
+        aligned = self.pcd_align(nbr_l, ref_l, ref_repeat=N, ref_block=self.center, sinks=sinks)   # [N*B, nf, H, W], frame-major
         return self._fuse_reconstruct(aligned.view(N, B, -1, H, W), x_center)
 
 

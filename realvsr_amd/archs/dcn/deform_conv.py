@@ -115,7 +115,8 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         self.conv_offset_mask.weight.data.zero_()
         self.conv_offset_mask.bias.data.zero_()
 
-    def forward(self, x, act=RF.ACT_NONE, slope=0.1):
+    def forward(self, x, act=RF.ACT_NONE, slope=0.1, sink=None):
+        """act / slope / sink are extensions (fused LeakyReLU epilogue; functional.GradSink of the sampled input)."""
         if self.extra_offset_mask:  # x = [input, features]
             x, feat = x[0], x[1]
         else:
@@ -125,7 +126,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         if fused:
             om = RF.conv2d(feat, self.conv_offset_mask)
             return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                               self.deformable_groups, act, slope)
+                               self.deformable_groups, act, slope, sink)
         # Everything the reference's architectures instantiate (EDVR_arch.py:73-74, TDAN_arch.py:29-41) is 3x3, groups=1,
         # "same" padding.  Other geometries have no HIP kernel here and there is deliberately no library fallback.
         raise RuntimeError('ModulatedDeformConvPack: only 3x3 / groups=1 / padding=dilation is implemented on the '

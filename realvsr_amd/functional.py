@@ -59,13 +59,46 @@ def _workspace(nbytes, device):
     return buf
 
 
+class GradSink:
+    """One gradient buffer for an activation that several fused operators consume.
+
+    Autograd sums the gradients of a tensor with k consumers by k - 1 out-of-place adds (3 passes over the tensor each; the
+    40 x 64 x 180 x 320 feature maps of the alignment stage have up to four consumers).  The kernels here can do that
+    sum themselves: the DCN backward accumulates atomically into whatever its grad_input buffer holds, and the
+    data-gradient convs take a fused residual that may be their own output buffer.  A GradSink is created per forward for such an
+    activation and handed to its consumers:
+      * a DEPOSITOR (every consumer but the owner) adds its gradient into `buf` in place and returns None to autograd;
+      * the OWNER -- the consumer created FIRST in forward, hence run LAST in backward -- adds its own gradient the same way,
+        closes the sink and returns the buffer: autograd sees one gradient, no adds, no zero fills.
+    If the engine ever ran the owner early, the late depositors see `closed` and return their gradients normally: the
+    result is the same sum, just through autograd's adds."""
+    __slots__ = ('buf', 'closed', 'shape')
+
+    def __init__(self, shape=None):
+        self.buf, self.closed, self.shape = None, False, (tuple(shape) if shape is not None else None)
+
+    def get(self, like):
+        """The buffer to accumulate into (zeros on first use), or None once the owner has run."""
+        if self.closed:
+            return None
+        if self.buf is None:
+            self.buf = torch.zeros_like(like)
+        return self.buf
+
+    def close(self):
+        self.closed = True
+        buf, self.buf = self.buf, None
+        return buf
+
+
 # ------------------------------------------------------------------------------------------ conv
 class _Conv2dFused(Function):
     """act(conv2d(cat(x1, x2), w) + b) [+ residual] [-> PixelShuffle(2)]"""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle):
+    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle, sink=None):
         _need_cuda(x1, x2, weight, bias, residual)
+        ctx.sink = sink   # GradSink of x1: this conv is its OWNER (see GradSink)
         x1, x2, weight, bias, residual = _c(x1), _c(x2), _c(weight), _c(bias), _c(residual)
         B, C1, H, W = x1.shape
         C2 = 0 if x2 is None else x2.shape[1]
@@ -100,12 +133,14 @@ class _Conv2dFused(Function):
         need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gx1 = gx2 = gw = gb = None
         if need_x1 or (x2 is not None and need_x2):
-            gx1 = torch.empty_like(x1)
+            # owner of a GradSink (single-input convs only): add this data gradient onto what the other consumers of x1 deposited
+            dep = ctx.sink.close() if (ctx.sink is not None and x2 is None) else None
+            gx1 = dep if dep is not None else torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
             in_mode = 2 if ps else (1 if stride == 2 else 0)
             ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1 + C2, k), x1.device)
             _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2],
-                                             gout.shape[3], _p(weight), None, None, _p(gx1), C1, _p(gx2), C2, B, k,
+                                             gout.shape[3], _p(weight), None, _p(dep), _p(gx1), C1, _p(gx2), C2, B, k,
                                              1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
                        'conv2d_backward_data')
         if need_w or (has_bias and ctx.needs_input_grad[3]):
@@ -118,7 +153,7 @@ class _Conv2dFused(Function):
                                                      Co, B, k, stride, Ho, Wo, 0, _p(ws), ws.numel(), _stream()),
                        'conv2d_backward_weight')
         gres = gout if has_res else None
-        return gx1, gx2, gw, gb, gres, None, None, None, None
+        return gx1, gx2, gw, gb, gres, None, None, None, None, None
 
 
 class _ResBlockFused(Function):
@@ -201,9 +236,12 @@ class _ConvCatBcast(Function):
     one reduction over N backward; act' is taken from the saved output as everywhere else."""
 
     @staticmethod
-    def forward(ctx, x, ref, weight, bias, N, act, slope):
+    def forward(ctx, x, ref, weight, bias, N, act, slope, x_sink=None, x_owner=False, ref_sink=None, ref_block=0):
         _need_cuda(x, ref, weight, bias)
         x, ref, weight, bias = _c(x), _c(ref), _c(weight), _c(bias)
+        # GradSinks (see GradSink): x_sink collects the gradient of x (this conv deposits, or owns it when x_owner);
+        # ref_sink is the sink of the [N*B] tensor whose block `ref_block` IS ref: the ref gradient is added into that block
+        ctx.sinks = (x_sink, bool(x_owner), ref_sink, int(ref_block))
         NB, C1, H, W = x.shape
         B, C2 = ref.shape[0], ref.shape[1]
         Co, Cw, k, _ = weight.shape
@@ -238,18 +276,34 @@ class _ConvCatBcast(Function):
         # gradient of the broadcast partial: sum over the N frames of gout * act'
         gpart = x.new_empty(B, Co, H, W)
         _lib.check(L.rvsr_bcast_reduce_act(_p(gout), _p(act_out), _p(gpart), gpart.numel(), N, gslope, _stream()), 'bcast_reduce_act')
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1, 3), x.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, 0, H, W, _p(w_a), None, None, _p(gx), C1,
-                                             None, 0, NB, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                       'conv_cat_bcast dgrad_a')
+        x_sink, x_owner, ref_sink, ref_block = ctx.sinks
+        # (the reference gradient first: when this conv owns x's sink and ref is a block of x, the deposit must precede the close)
         if ctx.needs_input_grad[1]:
-            gref = torch.empty_like(ref)
+            blk = None
+            if ref_sink is not None and not ref_sink.closed:
+                full = ref_sink.buf
+                if full is None:
+                    full = ref_sink.buf = ref.new_zeros(ref_sink.shape)
+                blk = full[ref_block * B:(ref_block + 1) * B]
+            gref = blk if blk is not None else torch.empty_like(ref)
             ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C2, 3), x.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gpart), Co, None, 0, None, 0.0, 0, H, W, _p(w_b), None, None, _p(gref), C2,
+            _lib.check(L.rvsr_conv2d_forward(_p(gpart), Co, None, 0, None, 0.0, 0, H, W, _p(w_b), None, _p(blk), _p(gref), C2,
                                              None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
                        'conv_cat_bcast dgrad_b')
+            if blk is not None:
+                gref = None  # deposited into the block of the full tensor's sink
+        if ctx.needs_input_grad[0]:
+            dep = None
+            if x_sink is not None:
+                dep = x_sink.close() if x_owner else x_sink.get(x)
+            gx = dep if dep is not None else torch.empty_like(x)
+            # a fresh sink buffer is all zeros: adding it as the residual is exact and keeps one code path
+            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1, 3), x.device)
+            _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, 0, H, W, _p(w_a), None, _p(dep), _p(gx), C1,
+                                             None, 0, NB, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
+                       'conv_cat_bcast dgrad_a')
+            if dep is not None and not x_owner:
+                gx = None    # deposited: the owner returns the buffer
         if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
             gw_a, gw_b = torch.empty_like(w_a), torch.empty_like(w_b)
             gb = w_a.new_empty(Co) if has_bias else None
@@ -261,12 +315,12 @@ class _ConvCatBcast(Function):
             _lib.check(L.rvsr_conv2d_backward_weight(_p(ref), C2, None, 0, H, W, _p(gpart), None, 0.0, 0, H, W, _p(gw_b), None,
                                                      Co, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast wgrad_b')
             gw = torch.cat([gw_a, gw_b], 1)
-        return gx, gref, gw, gb, None, None, None
+        return gx, gref, gw, gb, None, None, None, None, None, None, None
 
 
-def conv_cat_bcast(x, ref, conv, N, act=ACT_NONE, slope=0.1):
+def conv_cat_bcast(x, ref, conv, N, act=ACT_NONE, slope=0.1, x_sink=None, x_owner=False, ref_sink=None, ref_block=0):
     """act(conv(cat([x, ref.repeat(N, 1, 1, 1)], 1))) for frame-major x [N*B, ...] and ref [B, ...] (3x3, stride 1)."""
-    return _ConvCatBcast.apply(x, ref, conv.weight, conv.bias, int(N), act, float(slope))
+    return _ConvCatBcast.apply(x, ref, conv.weight, conv.bias, int(N), act, float(slope), x_sink, x_owner, ref_sink, ref_block)
 
 
 def res_block(x, conv1, conv2):
@@ -274,7 +328,7 @@ def res_block(x, conv1, conv2):
     return _ResBlockFused.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
 
 
-def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False):
+def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False, sink=None):
     """Fused conv block driven by an ``nn.Conv2d`` parameter holder (weight, bias, stride).
 
     out = act(conv(cat(x, x2))) [+ residual]; with ``pixel_shuffle`` the activation commutes with
@@ -282,9 +336,9 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
     stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
     if residual is not None and act != ACT_NONE:
         # act'(.) is recovered from the saved activation output, so the residual is added outside
-        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle)
+        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle, sink)
         return out + residual
-    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle)
+    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle, sink)
 
 
 # ------------------------------------------------------------------------------------------ DCN
@@ -352,9 +406,10 @@ class _DcnPackFused(Function):
     """DCN fed directly by the raw conv_offset_mask output (chunk/cat/sigmoid fused)."""
 
     @staticmethod
-    def forward(ctx, x, om, weight, bias, stride, padding, dilation, dg, act, slope):
+    def forward(ctx, x, om, weight, bias, stride, padding, dilation, dg, act, slope, sink=None):
         _need_cuda(x, om, weight, bias)
         x, om, weight, bias = _c(x), _c(om), _c(weight), _c(bias)
+        ctx.sink = sink   # GradSink of x: the DCN is a depositor (its backward accumulates atomically into the buffer)
         B, C, H, W = x.shape
         Co = weight.shape[0]
         if weight.shape[2:] != (3, 3):
@@ -381,7 +436,8 @@ class _DcnPackFused(Function):
         gout = gout.contiguous()
         B, C, H, W = x.shape
         Co = weight.shape[0]
-        gx = torch.zeros_like(x)
+        dep = ctx.sink.get(x) if ctx.sink is not None else None
+        gx = dep if dep is not None else torch.zeros_like(x)
         gom = torch.empty_like(om)
         gw = torch.zeros_like(weight)
         gb = weight.new_zeros(Co) if has_bias else None
@@ -392,11 +448,11 @@ class _DcnPackFused(Function):
         _lib.check(L.rvsr_dcn_pack_backward(_p(x), _p(weight), _p(om), _p(gout), _p(act_out), gslope, _p(gx), _p(gw),
                                             _p(gb), _p(gom), B, C, H, W, Co, stride, padding, dilation, dg, _p(ws),
                                             ws.numel(), _stream()), 'dcn_pack_backward')
-        return gx, gom, gw, gb, None, None, None, None, None, None
+        return (None if dep is not None else gx), gom, gw, gb, None, None, None, None, None, None, None
 
 
-def dcn_pack(x, om, weight, bias, stride, padding, dilation, deformable_groups, act=ACT_NONE, slope=0.1):
-    return _DcnPackFused.apply(x, om, weight, bias, stride, padding, dilation, deformable_groups, act, slope)
+def dcn_pack(x, om, weight, bias, stride, padding, dilation, deformable_groups, act=ACT_NONE, slope=0.1, sink=None):
+    return _DcnPackFused.apply(x, om, weight, bias, stride, padding, dilation, deformable_groups, act, slope, sink)
 
 
 # ------------------------------------------------------------------------------------------ resampling / fusion
