@@ -79,6 +79,61 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gout, float* __res
     }
 }
 
+// x2 specialisations (every upsample of the alignment stage: EDVR_arch.py:111-124): one thread per INPUT pixel, 32-bit index
+// math, constant weights.  Output rows 2y / 2y+1 read input rows (y-1, y) / (y, y+1) with weights (1/4, 3/4) / (3/4, 1/4); at
+// the borders the clamped source index folds the outer weight onto the edge row.  The generic kernels above (64-bit div/mod per
+// output element, per-element float divisions, 4x4 candidate scan) ran at 0.5 / 0.7 ms on the 40 x 64 x 90 x 160 -> 180 x 320
+// tensors against a 0.14 ms HBM floor.
+__global__ void upsample2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned planes, int H, int W, float scale) {
+    const unsigned n = planes * (unsigned)(H * W);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned pl = i / (unsigned)(H * W), rem = i - pl * (unsigned)(H * W);
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * W);
+        const float* p = in + (size_t)pl * H * W;
+        const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : H - 1;
+        const int xm = x > 0 ? x - 1 : 0, xp = x < W - 1 ? x + 1 : W - 1;
+        const float a00 = p[ym * W + xm], a01 = p[ym * W + x], a02 = p[ym * W + xp];
+        const float a10 = p[y * W + xm], a11 = p[y * W + x], a12 = p[y * W + xp];
+        const float a20 = p[yp * W + xm], a21 = p[yp * W + x], a22 = p[yp * W + xp];
+        // same association as the generic kernel: ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11)
+        const float wA0 = y > 0 ? 0.25f : 0.f, wA1 = y > 0 ? 0.75f : 1.f;           // output row 2y: rows (y-1, y)
+        const float wB0 = 0.75f, wB1 = 0.25f;                                           // output row 2y+1: rows (y, y+1 clamped)
+        const float uA0 = x > 0 ? 0.25f : 0.f, uA1 = x > 0 ? 0.75f : 1.f;            // output col 2x: cols (x-1, x)
+        const float uB0 = 0.75f, uB1 = 0.25f;                                           // output col 2x+1: cols (x, x+1 clamped)
+        float2 r0, r1;
+        r0.x = (wA0 * (uA0 * a00 + uA1 * a01) + wA1 * (uA0 * a10 + uA1 * a11)) * scale;
+        r0.y = (wA0 * (uB0 * a01 + uB1 * a02) + wA1 * (uB0 * a11 + uB1 * a12)) * scale;
+        r1.x = (wB0 * (uA0 * a10 + uA1 * a11) + wB1 * (uA0 * a20 + uA1 * a21)) * scale;
+        r1.y = (wB0 * (uB0 * a11 + uB1 * a12) + wB1 * (uB0 * a21 + uB1 * a22)) * scale;
+        float* o = out + (size_t)pl * 4 * H * W + (size_t)(2 * y) * (2 * W) + 2 * x;
+        *reinterpret_cast<float2*>(o) = r0;
+        *reinterpret_cast<float2*>(o + 2 * W) = r1;
+    }
+}
+// adjoint: input pixel (y, x) collects output rows 2y-1 .. 2y+2 with weights (1/4, 3/4, 3/4, 1/4), edge rows folded as above
+__global__ void upsample2_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, unsigned planes, int H, int W, float scale) {
+    const unsigned n = planes * (unsigned)(H * W);
+    const int Wo = 2 * W;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned pl = i / (unsigned)(H * W), rem = i - pl * (unsigned)(H * W);
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * W);
+        const float* g = gout + (size_t)pl * 4 * H * W;
+        const float wy[4] = {y > 0 ? 0.25f : 0.f, y > 0 ? 0.75f : 1.f, y < H - 1 ? 0.75f : 1.f, y < H - 1 ? 0.25f : 0.f};
+        const float wx[4] = {x > 0 ? 0.25f : 0.f, x > 0 ? 0.75f : 1.f, x < W - 1 ? 0.75f : 1.f, x < W - 1 ? 0.25f : 0.f};
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int oy = 2 * y - 1 + a;
+            oy = oy < 0 ? 0 : (oy > 2 * H - 1 ? 2 * H - 1 : oy);    // clamped rows carry weight 0
+            const float* row = g + (size_t)oy * Wo;
+            const float2 mid = *reinterpret_cast<const float2*>(row + 2 * x);        // cols 2x, 2x+1 (8-byte aligned)
+            const float l = row[x > 0 ? 2 * x - 1 : 0], r = row[x < W - 1 ? 2 * x + 2 : Wo - 1];
+            acc += wy[a] * (wx[0] * l + wx[1] * mid.x + wx[2] * mid.y + wx[3] * r);
+        }
+        gin[i] = acc * scale;
+    }
+}
+
 // ---------------------------------------------------------------- max+avg pool 3/2/1 -> cat
 __global__ void pool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned char* __restrict__ arg,
                                 int B, int C, int H, int W, int Ho, int Wo) {
@@ -393,6 +448,10 @@ extern "C" int rvsr_upsample_bilinear_forward(const float* in, float* out, size_
                                               float scale, void* stream) {
     if (!in || !out || (factor != 2 && factor != 4)) FAIL(RVSR_ERR_BAD_ARG, "upsample: bad argument (factor %d)", factor);
     const size_t n = planes * H * factor * W * factor;
+    if (factor == 2 && n < (1ull << 32) && (((uintptr_t)out) & 7) == 0) {
+        hipLaunchKernelGGL(upsample2_fwd_kernel, GRID_FOR(n / 4), dim3(256), 0, (hipStream_t)stream, in, out, (unsigned)planes, H, W, scale);
+        CHECK_LAUNCH("upsample2_fwd");
+    }
     hipLaunchKernelGGL(upsample_fwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, in, out, planes, H, W, factor, scale);
     CHECK_LAUNCH("upsample_fwd");
 }
@@ -400,6 +459,10 @@ extern "C" int rvsr_upsample_bilinear_backward(const float* gout, float* gin, si
                                                float scale, void* stream) {
     if (!gout || !gin || (factor != 2 && factor != 4)) FAIL(RVSR_ERR_BAD_ARG, "upsample backward: bad argument");
     const size_t n = planes * H * W;
+    if (factor == 2 && n * 4 < (1ull << 32) && (((uintptr_t)gout) & 7) == 0) {
+        hipLaunchKernelGGL(upsample2_bwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, gout, gin, (unsigned)planes, H, W, scale);
+        CHECK_LAUNCH("upsample2_bwd");
+    }
     hipLaunchKernelGGL(upsample_bwd_kernel, GRID_FOR(n), dim3(256), 0, (hipStream_t)stream, gout, gin, planes, H, W, factor, scale);
     CHECK_LAUNCH("upsample_bwd");
 }
