@@ -35,7 +35,7 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault('OMP_NUM_THREADS', str(os.cpu_count() or 1))  # CPU oracle threads (cpu_baseline)
+os.environ.setdefault('OMP_NUM_THREADS', str(min(os.cpu_count() or 1, 32)))  # CPU oracle threads (cpu_baseline)
 
 import torch
 
@@ -165,8 +165,7 @@ class _Proxy:
 
 def cpu_baseline(args):
     """One window (B=1) of the same workload through the CPU oracle: fwd + loss + bwd; BASELINE.md section 2 protocol
-    (1 warm-up, then best of 3).  The warm-up runs with every host core, a second probe with 32 threads (torch's CPU
-    conv path stops scaling well below 256 hardware threads); the faster setting is used for the timed runs."""
+    (1 warm-up, then best of 3)."""
     from oracle import edvr_oracle as O
     from realvsr_amd.archs.EDVR_arch import EDVR
     nf, N, H, W = args.nf, args.nframes, args.height, args.width
@@ -186,14 +185,13 @@ def cpu_baseline(args):
         loss.backward()
         return time.perf_counter() - t0
 
+    # Thread count: min(hardware threads, 32).  The torch CPU conv path collapses from oversubscription on this host: the same
+    # window took 432 s with all 256 hardware threads and 8.4 s with 32 (measured by an earlier version of this function, see
+    # profiles/r02_notes.md), so "all cores" would both misrepresent the CPU and blow the bench's time budget.
     ncpu = os.cpu_count() or 1
-    torch.set_num_threads(ncpu)
-    probe = {ncpu: one()}                       # warm-up (also the all-cores probe)
-    if ncpu > 32:
-        torch.set_num_threads(32)
-        probe[32] = one()
-    cores = min(probe, key=probe.get)
+    cores = min(ncpu, 32)
     torch.set_num_threads(cores)
+    one()                                       # warm-up
     best = min(one() for _ in range(3))
     cpu_model = ''
     try:
@@ -203,9 +201,8 @@ def cpu_baseline(args):
         pass
     return {'value': round(1.0 / best, 5), 'unit': 'HR frames/s', 'cores': cores, 'kind': 'port',
             'sample': '1 window (B=1, %d frames %dx%d LR) fwd+loss+bwd through oracle/edvr_oracle.py (torch %s CPU ops + '
-                      'OpenMP C DCN); 1 warm-up + best of 3 = %.2f s; host: %d hardware threads, %s; thread-count probe %s'
-                      % (N, H, W, torch.__version__, best, ncpu, cpu_model,
-                         {k: round(v, 2) for k, v in probe.items()})}
+                      'OpenMP C DCN); 1 warm-up + best of 3 = %.2f s; %d threads on a host with %d hardware threads (%s)'
+                      % (N, H, W, torch.__version__, best, cores, ncpu, cpu_model)}
 
 
 def relaunch(args):
