@@ -857,10 +857,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     Tile itile = tile_of(0);
     // geometry + bias of the stage's tile when a new tile starts (bias of tile k lives in slot k & 3: tiles k-1 .. k+1
     // can be alive at once when a tile is a single stage)
-    auto stage_tile = [&](int q) {
+    // (tile index, chunk index) of a stage are carried as counters: `q / nchunks` by a run-time divisor expands to ~25 vector
+    // instructions incl. quarter-rate integer multiplies, and the stage loop evaluated it seven times per stage -- in a loop
+    // whose SQ counters show 6.2 VALU instructions per MFMA (issue-bound, profiles/r02_notes.md)
+    auto stage_tile = [&](int q, int k, int ch) {
         if (q >= Q) return;
-        const int k = q / nchunks;
-        if (q - k * nchunks == 0) {
+        if (ch == 0) {
             itile = tile_of(k);
             item_geom(itile);
             if (tid < MP) {
@@ -869,19 +871,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             }
         }
     };
-    auto issue_stage = [&](int q, int wsel, int xsel) {
+    auto issue_stage = [&](int q, int ch, int wsel, int xsel) {
         if (q >= Q) return;
-        const int k = q / nchunks;
-        issue_loads(itile, q - k * nchunks, wsel, xsel);
+        issue_loads(itile, ch, wsel, xsel);
     };
 
     STAMP(60);
-    stage_tile(0);
-    issue_stage(0, -1, -1);
+    stage_tile(0, 0, 0);
+    issue_stage(0, 0, -1, -1);
     commit(0, -1, -1);
-    stage_tile(1);
-    issue_stage(1, -1, -1);
+    stage_tile(1, 1 / nchunks, 1 % nchunks);
+    issue_stage(1, 1 % nchunks, -1, -1);
     __syncthreads();
+    int k_cur = 0, c_cur = 0;                          // stage q
+    int k_nx2 = 2 / nchunks, c_nx2 = 2 % nchunks;      // stage q + 2
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -937,8 +940,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 if (pub) commit(buf ^ 1, NWV, tap);
             } else {
                 if (pub) commit(buf ^ 1, tap - 4, 8);
-                if (tap == 4) stage_tile(q + 2);
-                issue_stage(q + 2, tap - 4, VEC ? (tap < 6 ? tap - 4 : 8) : (tap - 4 < NIT ? tap - 4 : 8));
+                if (tap == 4) stage_tile(q + 2, k_nx2, c_nx2);
+                issue_stage(q + 2, c_nx2, tap - 4, VEC ? (tap < 6 ? tap - 4 : 8) : (tap - 4 < NIT ? tap - 4 : 8));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -947,8 +950,11 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         if (blockIdx.x == 77 && lane == 0 && q == Q - 3) rvsr_dbg[70 + wave] = __builtin_amdgcn_s_memtime();
         if (blockIdx.x == 77 && lane == 0 && q == Q - 4) rvsr_dbg[90 + wave] = __builtin_amdgcn_s_memtime();
 #endif
-        const int k = q / nchunks;
-        if (q - k * nchunks == nchunks - 1) {  // last chunk of tile k: epilogue, fresh accumulators
+        const int k = k_cur;
+        const bool last_chunk = c_cur == nchunks - 1;
+        if (++c_cur == nchunks) { c_cur = 0; ++k_cur; }
+        if (++c_nx2 == nchunks) { c_nx2 = 0; ++k_nx2; }
+        if (last_chunk) {  // last chunk of tile k: epilogue, fresh accumulators
             const Tile cur = tile_of(k);
             const float* bias_s = bias_base + (k & 3) * MP;
             if (p.ps)
