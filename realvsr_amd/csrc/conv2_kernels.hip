@@ -1233,11 +1233,20 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     // issues one part per k-step of the MFMA phase so the requests trickle out under the matrix work instead of as one
     // burst in front of it (the burst took ~5.5 K cycles to issue: the memory pipeline back-pressures).
     // parts 0-3: X item `part`; parts 4, 5: G item 0, 1; parts 6, 7: nothing.
-    auto issue_loads = [&](int tile, int part) {
-        const int b = tile / (p.nty * p.ntx);
-        const int trem = tile - b * (p.nty * p.ntx);
-        const int ty = trem / p.ntx, tx = trem - ty * p.ntx;
-        const int y0 = ty * 4, x0 = tx * 32;
+    // tile -> (image, row, column) once per tile: issue_loads runs eight times per tile (a slice per MFMA k-step) and two
+    // run-time divisions per call were ~400 vector instructions per tile inside the MFMA loop
+    struct TilePos { int b, y0, x0; };
+    auto tile_pos = [&](int tile) {
+        TilePos t;
+        t.b = tile / (p.nty * p.ntx);
+        const int trem = tile - t.b * (p.nty * p.ntx);
+        const int ty = trem / p.ntx;
+        t.y0 = ty * 4;
+        t.x0 = (trem - ty * p.ntx) * 32;
+        return t;
+    };
+    auto issue_loads = [&](const TilePos& tp, int part) {
+        const int b = tp.b, y0 = tp.y0, x0 = tp.x0;
         if (part < 0 || part == 4) gok = 0;
         if (part <= 0) xok = 0;
         const float* gimg = p.g.p + (size_t)b * img_g;
@@ -1353,8 +1362,9 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     const int ntiles = p.B * p.nty * p.ntx;
     const int per = (ntiles + p.P - 1) / p.P;
     const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
-    if (t_begin < t_end) issue_loads(t_begin, -1);
+    if (t_begin < t_end) issue_loads(tile_pos(t_begin), -1);
     for (int tile = t_begin; tile < t_end; ++tile) {
+        const TilePos next_pos = tile_pos(tile + 1 < t_end ? tile + 1 : tile);
         const int ti = tile - t_begin;
         if (ti < 6) STAMP(100 + ti * 5);
         commit();
@@ -1363,11 +1373,11 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         if (ti < 6) STAMP(102 + ti * 5);
         if (ti < 6) STAMP(103 + ti * 5);
         const bool more = tile + 1 < t_end;
-        if (!m_live && more) issue_loads(tile + 1, -1);
+        if (!m_live && more) issue_loads(next_pos, -1);
         if (m_live) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                if (more) issue_loads(tile + 1, ks);
+                if (more) issue_loads(next_pos, ks);
                 __builtin_amdgcn_sched_barrier(0);
                 const int row = ks >> 1, cb = (ks & 1) * 16 + 8 * hi;  // this lane's 8 pixels: row, cols cb..cb+7
                 const int goff = (m * 32 + lo) * WG2_GP + row * 64 + cb * 2;
