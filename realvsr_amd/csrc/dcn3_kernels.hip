@@ -80,6 +80,20 @@ __device__ __forceinline__ void xtile16x40_commit(float4* xt, const XTile16x40& 
                                     left > 3 ? r.v[4][3] : 0.f);
 }
 
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lo2(const float4& a) { return f32x2{a.x, a.y}; }
+__device__ __forceinline__ f32x2 hi2(const float4& a) { return f32x2{a.z, a.w}; }
+// s.x * a00 + t.x * a01 + s.y * a10 + t.y * a11 on a pair of channels (VOP3P op_sel / op_sel_hi pick the broadcast half)
+__device__ __forceinline__ f32x2 blend4(f32x2 s, f32x2 t, f32x2 a00, f32x2 a01, f32x2 a10, f32x2 a11) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(s), "v"(a00));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(r) : "v"(t), "v"(a01));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(r) : "v"(s), "v"(a10));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(r) : "v"(t), "v"(a11));
+    return r;
+}
+
 template <int MT>
 __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
@@ -167,20 +181,20 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
             const float ly = yr - fy, lx = xr_ - fx;
             // 2x2 footprint inside the tile <=> 0 <= r0 <= TR-2 and 0 <= s0 <= TC-2 (NaN/huge offsets fail the test)
             const bool in_tile = (unsigned)r0 < (unsigned)(TR - 1) && (unsigned)s0 < (unsigned)(TC - 1);
-            const float wy1 = ly * m, wy0 = m - wy1;
-            const float w01 = wy0 * lx, w00 = wy0 - w01, w11 = wy1 * lx, w10 = wy1 - w11;
+            // corner weights (x mask) as two register pairs S = (w00, w10), T = (w01, w11); the four-corner blend of a
+            // channel pair is then four packed ops with one weight broadcast each.  Spelled in assembly: left to itself the
+            // compiler pairs the first channels ACROSS corners and spends 14 v_mov per tap rearranging registers.
+            const float wy1 = ly * m;
+            const f32x2 wy = {m - wy1, wy1};
+            const f32x2 wt = wy * lx, wsd = wy - wt;
             const int pos = in_tile ? r0 * TC + s0 : 0;
             const float4 a00 = xq0[pos], b00 = xq0[NPOS + pos], a01 = xq0[pos + 1], b01 = xq0[NPOS + pos + 1];
             const float4 a10 = xq0[pos + TC], b10 = xq0[NPOS + pos + TC], a11 = xq0[pos + TC + 1], b11 = xq0[NPOS + pos + TC + 1];
-            float v[8];
-            v[0] = w00 * a00.x + w01 * a01.x + w10 * a10.x + w11 * a11.x;
-            v[1] = w00 * a00.y + w01 * a01.y + w10 * a10.y + w11 * a11.y;
-            v[2] = w00 * a00.z + w01 * a01.z + w10 * a10.z + w11 * a11.z;
-            v[3] = w00 * a00.w + w01 * a01.w + w10 * a10.w + w11 * a11.w;
-            v[4] = w00 * b00.x + w01 * b01.x + w10 * b10.x + w11 * b11.x;
-            v[5] = w00 * b00.y + w01 * b01.y + w10 * b10.y + w11 * b11.y;
-            v[6] = w00 * b00.z + w01 * b01.z + w10 * b10.z + w11 * b11.z;
-            v[7] = w00 * b00.w + w01 * b01.w + w10 * b10.w + w11 * b11.w;
+            const f32x2 p0 = blend4(wsd, wt, lo2(a00), lo2(a01), lo2(a10), lo2(a11));
+            const f32x2 p1 = blend4(wsd, wt, hi2(a00), hi2(a01), hi2(a10), hi2(a11));
+            const f32x2 p2 = blend4(wsd, wt, lo2(b00), lo2(b01), lo2(b10), lo2(b11));
+            const f32x2 p3 = blend4(wsd, wt, hi2(b00), hi2(b01), hi2(b10), hi2(b11));
+            float v[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
             if (!in_tile && oct_ok) {
                 // large offset: this lane gathers its corners from global memory, with the reference's rules spelled out
                 // (image coordinates; kernel.cu:467-497,618)
