@@ -94,6 +94,11 @@ __device__ __forceinline__ f32x2 blend4(f32x2 s, f32x2 t, f32x2 a00, f32x2 a01, 
     return r;
 }
 
+// buffer_load_dword v, v_byte_offset, s[rsrc], s_byte_offset offen
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_bytes, (int)uniform_bytes, 0));
+}
+
 template <int MT>
 __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
@@ -122,6 +127,10 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
     // moved into tile coordinates.
     const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
 
+    // raw buffer views of this batch element's offset / mask planes (rvsr_launch_dcn_fwd3 checks that they span < 4 GB)
+    const __amdgpu_buffer_rsrc_t off_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.offset + (size_t)b * d.off_bs), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t msk_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.mask + (size_t)b * d.mask_bs), 0, 0xfffffffc, 0x00020000);
+
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = zero16();
@@ -131,11 +140,13 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
         const int c0 = chunk * 16;
         const int cb8 = c0 + 8 * hi;              // first channel of this lane's octet
         const bool oct_ok = px_ok && cb8 < d.C;
-        const int g = oct_ok ? cb8 / d.cpg : 0;
-        const size_t pixc = oct_ok ? pix : 0;     // lanes without work read pixel 0 (loads stay unconditional)
-        const float* offp = d.offset + (size_t)b * d.off_bs + (size_t)(g * 18) * hw + pixc;
-        const float* mskp = d.mask + (size_t)b * d.mask_bs + (size_t)(g * 9) * hw + pixc;
-        float n_dy = offp[0], n_dx = offp[hw], n_m = mskp[0];
+        // offsets / mask: buffer loads with a uniform (SGPR) plane offset and a 32-bit per-lane byte offset -- no per-lane
+        // 64-bit address arithmetic in the tap loop (three v_lshl_add_u64 per tap otherwise)
+        const int g0 = c0 / d.cpg, dg = oct_ok ? cb8 / d.cpg - g0 : 0;
+        const unsigned pixc = oct_ok ? (unsigned)pix : 0u;   // lanes without work read pixel 0 (loads stay unconditional)
+        const unsigned off_lane = 4u * (pixc + (unsigned)(dg * 18) * (unsigned)hw), msk_lane = 4u * (pixc + (unsigned)(dg * 9) * (unsigned)hw);
+        const unsigned off_pl = 4u * (unsigned)(g0 * 18) * (unsigned)hw, msk_pl = 4u * (unsigned)(g0 * 9) * (unsigned)hw, pl = 4u * (unsigned)hw;
+        float n_dy = buf_load(off_rs, off_lane, off_pl), n_dx = buf_load(off_rs, off_lane, off_pl + pl), n_m = buf_load(msk_rs, msk_lane, msk_pl);
         {   // weight slice + x tile of the chunk: ALL global loads first, then the LDS writes (one round trip)
             // weight slice: LDS-DMA (global_load_lds_dwordx4: lane l of a wave lands at M0 + 16 l, so a linear copy needs
             // no registers, no ds_write and no wait before the barrier's)
@@ -169,9 +180,9 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
             const float dy = n_dy, dx = n_dx;
             float m = n_m;
             if (tap < 8) {  // (compile-time) prefetch the next tap's offsets/mask under this tap's math
-                n_dy = offp[(size_t)(2 * tap + 2) * hw];
-                n_dx = offp[(size_t)(2 * tap + 3) * hw];
-                n_m = mskp[(size_t)(tap + 1) * hw];
+                n_dy = buf_load(off_rs, off_lane, off_pl + (unsigned)(2 * tap + 2) * pl);
+                n_dx = buf_load(off_rs, off_lane, off_pl + (unsigned)(2 * tap + 3) * pl);
+                n_m = buf_load(msk_rs, msk_lane, msk_pl + (unsigned)(tap + 1) * pl);
             }
             if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));  // (uniform)
             m = oct_ok ? m : 0.f;                                            // lanes without work contribute zeros
@@ -303,6 +314,8 @@ static int launch_dcn_fwd3(const DcnFwdParams& p, const bf16x8* wpack, hipStream
 int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st) {
     const DcnGeom& d = p.d;
     if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
+    // 32-bit byte offsets into one batch element's offset planes (18 per deformable group): larger frames take dcn_fwd2
+    if ((size_t)(d.C / d.cpg) * 18 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 32)) return RVSR_ERR_UNSUPPORTED;
     const bf16x8* wp = (const bf16x8*)wpack;
     if (mt == 1) return launch_dcn_fwd3<1>(p, wp, st);
     if (mt == 2) return launch_dcn_fwd3<2>(p, wp, st);
