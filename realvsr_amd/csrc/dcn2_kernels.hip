@@ -1325,7 +1325,9 @@ static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* wo
     constexpr int TR = D3_TH + D3_PR - 1, PPOS = D3_PR * D3_TC;
     const size_t lds = (size_t)16 * (2 * TR * D3_TC + D3_TH * 2 * PPOS + 3 * 2 * (2 * NK) * 32) + (size_t)4 * D3_TH * 2 * PPOS;
     static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 4; }();  // developer A/B switch
-    auto k = gen >= 4 ? dcn_bwdin4_kernel<NK> : dcn_bwdin3_kernel<NK>;
+    // dcn_bwdin4 addresses one batch element's planes with 32-bit byte offsets (raw buffers): larger frames take dcn_bwdin3
+    const size_t span = sizeof(float) * (size_t)d.Ho * d.Wo * (size_t)((d.C / d.cpg) * 18 > d.C ? (d.C / d.cpg) * 18 : d.C);
+    auto k = gen >= 4 && span < ((size_t)1 << 32) ? dcn_bwdin4_kernel<NK> : dcn_bwdin3_kernel<NK>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin3: cannot reserve %zu B of LDS", lds);
     dim3 grid(d.ntx * ((d.Ho + D3_TH - 1) / D3_TH), 1, d.B);
     hipLaunchKernelGGL(k, grid, dim3(D3_TH * 64), lds, st, p, (const bf16x8*)workspace);

@@ -94,11 +94,6 @@ __device__ __forceinline__ f32x2 blend4(f32x2 s, f32x2 t, f32x2 a00, f32x2 a01, 
     return r;
 }
 
-// buffer_load_dword v, v_byte_offset, s[rsrc], s_byte_offset offen
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_bytes, (int)uniform_bytes, 0));
-}
-
 template <int MT>
 __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
@@ -128,8 +123,8 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
     const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
 
     // raw buffer views of this batch element's offset / mask planes (rvsr_launch_dcn_fwd3 checks that they span < 4 GB)
-    const __amdgpu_buffer_rsrc_t off_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.offset + (size_t)b * d.off_bs), 0, 0xfffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t msk_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.mask + (size_t)b * d.mask_bs), 0, 0xfffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs);
+    const __amdgpu_buffer_rsrc_t msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
 
     f32x16 acc[MT];
 #pragma unroll

@@ -221,3 +221,20 @@ static inline int set_lds(K kernel, size_t bytes) {
     last_dev[slot] = dev;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Raw buffer addressing: `buffer_* v, v_byte_offset, s[rsrc], s_byte_offset offen`.  A tensor plane is addressed as a uniform
+// (SGPR) byte offset of the plane plus a 32-bit per-lane byte offset inside it, so the inner loops carry no per-lane 64-bit
+// address arithmetic (v_lshl_add_u64 / v_mad_u64_u32 per access otherwise).  Callers check that the view spans < 4 GB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_view(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xfffffffc, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_bytes, (int)uniform_bytes, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, (int)lane_bytes, (int)uniform_bytes, 0);
+}
+__device__ __forceinline__ void buf_atomic_add(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rs, (int)lane_bytes, (int)uniform_bytes, 0);
+}
