@@ -288,7 +288,37 @@ struct DcnBwdIn2Params {
     size_t goff_bs, gmask_bs;
     int o_base, o_cnt;  // dcn_bwdin3 only: the pass covers output channels o_base .. o_base + o_cnt - 1 (o_cnt <= 64)
     int accum;          // dcn_bwdin3 only: a later pass of the same call: add to grad_offset / grad_mask instead of overwriting
+    // Kernel selection on the device (rvsr_launch_dcn_bwdin_auto): both generations are launched, each returns at once
+    // unless the sampled count of large offset components is on its side of the threshold.  nullptr: always run.
+    const unsigned* probe;
+    unsigned probe_thr;
+    int probe_far;      // 1: run when *probe > probe_thr (offset-heavy input), 0: run otherwise
 };
+__device__ __forceinline__ bool bwdin_not_selected(const DcnBwdIn2Params& p) {
+    return p.probe != nullptr && ((*p.probe > p.probe_thr) != (p.probe_far != 0));
+}
+
+// Sampled statistic behind that selection: every 16th row of every offset plane, count of components with |v| > 2.5 px
+// (beyond what dcn_bwdin3/4's private windows cover on either side).  ~1/16 of the offset planes is read.
+__global__ void dcn_offset_probe_kernel(const float* __restrict__ off, size_t off_bs, int B, int planes, int Ho, int Wo,
+                                        unsigned* __restrict__ cnt) {
+    const int nrow = (Ho + 15) / 16;
+    const size_t total = (size_t)B * planes * nrow * Wo;
+    unsigned mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        size_t r = i / Wo;
+        const int row = (int)(r % nrow);
+        r /= nrow;
+        const int pl = (int)(r % planes), b = (int)(r / planes);
+        const int y = row * 16 + 8 < Ho ? row * 16 + 8 : Ho - 1;
+        const float v = off[(size_t)b * off_bs + ((size_t)pl * Ho + y) * Wo + x];
+        mine += fabsf(v) > 2.5f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mine += __shfl_xor(mine, s);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(cnt, mine);
+}
 
 template <int TH, int NK>
 __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2Params p, const bf16x8* __restrict__ wpack) {
@@ -301,6 +331,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
     // hit consecutive banks (a float4-per-position layout is a 4-way conflict on every atomic)
     float* gt = reinterpret_cast<float*>(xt + 4 * NPOS);
     bf16x8* wsb = reinterpret_cast<bf16x8*>(gt + 16 * NPOS);  // [5][WBLK]
+    if (bwdin_not_selected(p)) return;
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
@@ -499,11 +530,14 @@ static int launch_bwdin2(const DcnBwdIn2Params& p, const float* weight, void* wo
 }
 
 int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
+                           const unsigned* probe, unsigned probe_thr) {
     if (d.cpg % 8 != 0 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin2_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     DcnBwdIn2Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
+    p.o_base = 0; p.o_cnt = d.Co; p.accum = 0;
+    p.probe = probe; p.probe_thr = probe_thr; p.probe_far = 1;
     if (d.Co <= 16) return launch_bwdin2<1>(p, weight, workspace, st);
     if (d.Co <= 32) return launch_bwdin2<2>(p, weight, workspace, st);
     if (d.Co <= 64) return launch_bwdin2<4>(p, weight, workspace, st);
@@ -1060,6 +1094,7 @@ __global__ __launch_bounds__(D3_TH * 64, 2) void dcn_bwdin3_kernel(const DcnBwdI
     float4* priv = xt + 2 * NPOS;                                  // [8 waves][2 quads][PPOS]
     int* claim = reinterpret_cast<int*>(priv + D3_TH * 2 * PPOS);  // [8 waves][2 quads][PPOS]
     bf16x8* wsb = reinterpret_cast<bf16x8*>(claim + D3_TH * 2 * PPOS);  // [3][WBLK]
+    if (bwdin_not_selected(p)) return;
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     unsigned sbx, sby, sbz;
@@ -1337,7 +1372,8 @@ static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* wo
 }
 
 int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
+                           const unsigned* probe, unsigned probe_thr) {
     // More than 64 output channels would need a 49 KB weight block on top of the private windows (> 160 KB of LDS) and
     // 64 more registers of gOut fragments: they are handled as passes of <= 64 output channels.  Everything downstream
     // of col_grad = W^T gOut is linear in it, so the passes simply add up (grad_input through the atomics it uses anyway,
@@ -1347,6 +1383,7 @@ int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin3_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     DcnBwdIn2Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
+    p.probe = probe; p.probe_thr = probe_thr; p.probe_far = 0;
     for (int ob = 0; ob < d.Co; ob += 64) {
         p.o_base = ob;
         p.o_cnt = d.Co - ob < 64 ? d.Co - ob : 64;
@@ -1360,4 +1397,35 @@ int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g
         if (rc != RVSR_OK) return rc;
     }
     return RVSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Offset-aware choice between the two generations, without a host round trip.  dcn_bwdin3/4 scatter through per-wave private
+// windows that cover offsets of about +-2 px; beyond them every sample costs 16 global atomics and 16 gathers, and the step time
+// at a mean |offset| of 2 / 3 / 5 px was 181 / 240 / 327 ms against 117 at ~0 px.  dcn_bwdin2 (shared LDS tile, ds_add_f32,
+// +-3 px) is 2.2x slower at small offsets but flat up to ~3 px: 181 / 180 / 236 ms at the same three points.  A sampled
+// statistic of the offsets decides on the device; both kernels are enqueued and the one not selected returns immediately
+// (~25 us per call for memset + probe + the empty launch).
+size_t rvsr_dcn_bwdin_auto_workspace_bytes(int Co, int C) {
+    const size_t a3 = (rvsr_dcn_bwdin3_workspace_bytes(Co, C) + 255) & ~(size_t)255;
+    const size_t a2 = (rvsr_dcn_bwdin2_workspace_bytes(Co, C) + 255) & ~(size_t)255;
+    return a3 + a2 + 256;
+}
+int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                               float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (!workspace || workspace_bytes < rvsr_dcn_bwdin_auto_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
+    if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
+    const size_t a3 = (rvsr_dcn_bwdin3_workspace_bytes(d.Co, d.C) + 255) & ~(size_t)255;
+    const size_t a2 = (rvsr_dcn_bwdin2_workspace_bytes(d.Co, d.C) + 255) & ~(size_t)255;
+    unsigned char* ws = (unsigned char*)workspace;
+    unsigned* cnt = (unsigned*)(ws + a3 + a2);
+    if (hipMemsetAsync(cnt, 0, sizeof(unsigned), st) != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward: memset of the probe counter failed");
+    const int planes = (d.C / d.cpg) * 18, nrow = (d.Ho + 15) / 16;
+    const size_t total = (size_t)d.B * planes * nrow * d.Wo;
+    const unsigned thr = (unsigned)(total / 4);   // P(|v| > 2.5 px) = 0.25 <=> Gaussian offsets of std 2.2 px (mean |v| 1.75 px)
+    const unsigned nb = (unsigned)((total + 2047) / 2048 < 2048 ? (total + 2047) / 2048 : 2048);
+    hipLaunchKernelGGL(dcn_offset_probe_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, d.offset, d.off_bs, d.B, planes, d.Ho, d.Wo, cnt);
+    int rc = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws, a3, st, cnt, thr);
+    if (rc != RVSR_OK) return rc;
+    return rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws + a3, a2, st, cnt, thr);
 }
