@@ -288,14 +288,15 @@ struct DcnBwdIn2Params {
     size_t goff_bs, gmask_bs;
     int o_base, o_cnt;  // dcn_bwdin3 only: the pass covers output channels o_base .. o_base + o_cnt - 1 (o_cnt <= 64)
     int accum;          // dcn_bwdin3 only: a later pass of the same call: add to grad_offset / grad_mask instead of overwriting
-    // Kernel selection on the device (rvsr_launch_dcn_bwdin_auto): both generations are launched, each returns at once
-    // unless the sampled count of large offset components is on its side of the threshold.  nullptr: always run.
+    // Kernel selection on the device (rvsr_launch_dcn_bwdin_auto): every candidate is launched and returns at once unless
+    // the sampled count of large offset components lies in its range.  nullptr: always run.
     const unsigned* probe;
-    unsigned probe_thr;
-    int probe_far;      // 1: run when *probe > probe_thr (offset-heavy input), 0: run otherwise
+    unsigned probe_lo, probe_hi;   // run when probe_lo <= *probe < probe_hi
 };
 __device__ __forceinline__ bool bwdin_not_selected(const DcnBwdIn2Params& p) {
-    return p.probe != nullptr && ((*p.probe > p.probe_thr) != (p.probe_far != 0));
+    if (p.probe == nullptr) return false;
+    const unsigned c = *p.probe;
+    return c < p.probe_lo || c >= p.probe_hi;
 }
 
 // Sampled statistic behind that selection: every 16th row of every offset plane, count of components with |v| > 2.5 px
@@ -320,10 +321,11 @@ __global__ void dcn_offset_probe_kernel(const float* __restrict__ off, size_t of
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(cnt, mine);
 }
 
-template <int TH, int NK>
+// BR: halo of the shared tile in pixels (offsets beyond it go to global memory); 3 by default, 5 for offset-heavy inputs
+template <int TH, int NK, int BR>
 __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2Params p, const bf16x8* __restrict__ wpack) {
     constexpr int NT = TH * 64;
-    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    constexpr int TR = TH + 2 * BR + 2, TC = 32 + 2 * BR + 2, NPOS = TR * TC;
     constexpr int WBLK = 2 * (2 * NK) * 32;  // vectors per (chunk, tap-pair) block (hi + lo)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);   // [4 quads][NPOS]   x tile of the chunk
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdin2_kernel(const DcnBwdIn2P
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int tx = blockIdx.x % d.ntx, ty = blockIdx.x / d.ntx;
     const int x0 = tx * 32, y0 = ty * TH, b = blockIdx.z;
-    const int ty0 = y0 * d.stride - d.pad - D2_R, tx0 = x0 * d.stride - d.pad - D2_R;
+    const int ty0 = y0 * d.stride - d.pad - BR, tx0 = x0 * d.stride - d.pad - BR;
     const int nchunks = (d.C + 15) / 16;
     const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
     const int oy = y0 + wave, ox = x0 + lo;
@@ -510,17 +512,17 @@ size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C) {
     return (size_t)((C + 15) / 16) * 5 * 2 * (2 * nk) * 32 * 16;
 }
 
-template <int NK>
+template <int NK, int BR>
 static int launch_bwdin2(const DcnBwdIn2Params& p, const float* weight, void* workspace, hipStream_t st) {
     constexpr int TH = 8;
-    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    constexpr int TR = TH + 2 * BR + 2, TC = 32 + 2 * BR + 2;
     const DcnGeom& d = p.d;
     const int nchunks = (d.C + 15) / 16;
     const size_t total = (size_t)nchunks * 5 * (2 * NK) * 32;
     hipLaunchKernelGGL(pack_weights_bwd_kernel<NK>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight,
                        (bf16x8*)workspace, d.Co, d.C, nchunks);
     const size_t lds = (size_t)16 * (8 * TR * TC + 5 * 2 * (2 * NK) * 32);
-    auto k = dcn_bwdin2_kernel<TH, NK>;
+    auto k = dcn_bwdin2_kernel<TH, NK, BR>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin2: cannot reserve %zu B of LDS", lds);
     dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), 1, d.B);
     hipLaunchKernelGGL(k, grid, dim3(TH * 64), lds, st, p, (const bf16x8*)workspace);
@@ -531,17 +533,22 @@ static int launch_bwdin2(const DcnBwdIn2Params& p, const float* weight, void* wo
 
 int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
-                           const unsigned* probe, unsigned probe_thr) {
+                           const unsigned* probe, unsigned probe_lo, unsigned probe_hi, int halo) {
     if (d.cpg % 8 != 0 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin2_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     DcnBwdIn2Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
     p.o_base = 0; p.o_cnt = d.Co; p.accum = 0;
-    p.probe = probe; p.probe_thr = probe_thr; p.probe_far = 1;
-    if (d.Co <= 16) return launch_bwdin2<1>(p, weight, workspace, st);
-    if (d.Co <= 32) return launch_bwdin2<2>(p, weight, workspace, st);
-    if (d.Co <= 64) return launch_bwdin2<4>(p, weight, workspace, st);
-    return launch_bwdin2<8>(p, weight, workspace, st);
+    p.probe = probe; p.probe_lo = probe_lo; p.probe_hi = probe_hi;
+    if (halo == 5 && d.Co <= 64) {   // wider halo (153 KB of LDS at NK = 4): pays off from a mean |offset| of ~4 px
+        if (d.Co <= 16) return launch_bwdin2<1, 5>(p, weight, workspace, st);
+        if (d.Co <= 32) return launch_bwdin2<2, 5>(p, weight, workspace, st);
+        return launch_bwdin2<4, 5>(p, weight, workspace, st);
+    }
+    if (d.Co <= 16) return launch_bwdin2<1, D2_R>(p, weight, workspace, st);
+    if (d.Co <= 32) return launch_bwdin2<2, D2_R>(p, weight, workspace, st);
+    if (d.Co <= 64) return launch_bwdin2<4, D2_R>(p, weight, workspace, st);
+    return launch_bwdin2<8, D2_R>(p, weight, workspace, st);
 }
 
 // ==========================================================================================
@@ -1373,7 +1380,7 @@ static int launch_bwdin3(const DcnBwdIn2Params& p, const float* weight, void* wo
 
 int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
-                           const unsigned* probe, unsigned probe_thr) {
+                           const unsigned* probe, unsigned probe_lo, unsigned probe_hi) {
     // More than 64 output channels would need a 49 KB weight block on top of the private windows (> 160 KB of LDS) and
     // 64 more registers of gOut fragments: they are handled as passes of <= 64 output channels.  Everything downstream
     // of col_grad = W^T gOut is linear in it, so the passes simply add up (grad_input through the atomics it uses anyway,
@@ -1383,7 +1390,7 @@ int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin3_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     DcnBwdIn2Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
-    p.probe = probe; p.probe_thr = probe_thr; p.probe_far = 0;
+    p.probe = probe; p.probe_lo = probe_lo; p.probe_hi = probe_hi;
     for (int ob = 0; ob < d.Co; ob += 64) {
         p.o_base = ob;
         p.o_cnt = d.Co - ob < 64 ? d.Co - ob : 64;
@@ -1405,7 +1412,8 @@ int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g
 // at a mean |offset| of 2 / 3 / 5 px was 181 / 240 / 327 ms against 117 at ~0 px.  dcn_bwdin2 (shared LDS tile, ds_add_f32,
 // +-3 px) is 2.2x slower at small offsets but flat up to ~3 px: 181 / 180 / 236 ms at the same three points.  A sampled
 // statistic of the offsets decides on the device; both kernels are enqueued and the one not selected returns immediately
-// (~25 us per call for memset + probe + the empty launch).
+// (~25 us per call for memset + probe + the empty launches).  From a mean |offset| of ~4 px dcn_bwdin2 runs with a 5 px halo
+// (153 KB of LDS): 5 px 234 -> 198 ms, 8 px 345 -> 308; at 2-3 px the 3 px halo is 1.5 % faster (smaller tile to stage and flush).
 size_t rvsr_dcn_bwdin_auto_workspace_bytes(int Co, int C) {
     const size_t a3 = (rvsr_dcn_bwdin3_workspace_bytes(Co, C) + 255) & ~(size_t)255;
     const size_t a2 = (rvsr_dcn_bwdin2_workspace_bytes(Co, C) + 255) & ~(size_t)255;
@@ -1422,10 +1430,13 @@ int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TVie
     if (hipMemsetAsync(cnt, 0, sizeof(unsigned), st) != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward: memset of the probe counter failed");
     const int planes = (d.C / d.cpg) * 18, nrow = (d.Ho + 15) / 16;
     const size_t total = (size_t)d.B * planes * nrow * d.Wo;
-    const unsigned thr = (unsigned)(total / 4);   // P(|v| > 2.5 px) = 0.25 <=> Gaussian offsets of std 2.2 px (mean |v| 1.75 px)
+    // P(|v| > 2.5 px) = 0.25 <=> Gaussian offsets of std 2.2 px (mean |v| 1.75 px); 0.55 <=> std 4.2 px (mean 3.3 px)
+    const unsigned thr = (unsigned)(total / 4), thr2 = d.Co <= 64 ? (unsigned)(total * 11 / 20) : 0xffffffffu;
     const unsigned nb = (unsigned)((total + 2047) / 2048 < 2048 ? (total + 2047) / 2048 : 2048);
     hipLaunchKernelGGL(dcn_offset_probe_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, d.offset, d.off_bs, d.B, planes, d.Ho, d.Wo, cnt);
-    int rc = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws, a3, st, cnt, thr);
+    int rc = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws, a3, st, cnt, 0, thr);
     if (rc != RVSR_OK) return rc;
-    return rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws + a3, a2, st, cnt, thr);
+    rc = rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws + a3, a2, st, cnt, thr, thr2, 3);
+    if (rc != RVSR_OK || thr2 == 0xffffffffu) return rc;
+    return rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, ws + a3, a2, st, cnt, thr2, 0xffffffffu, 5);
 }

@@ -87,13 +87,13 @@ int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipSt
 size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
-                           const unsigned* probe = nullptr, unsigned probe_thr = 0);
+                           const unsigned* probe = nullptr, unsigned probe_lo = 0, unsigned probe_hi = 0xffffffffu, int halo = 3);
 int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* bpart_or_null, int P, int nty, int gy, int gz,
                           hipStream_t st);
 size_t rvsr_dcn_bwdin3_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
-                           const unsigned* probe = nullptr, unsigned probe_thr = 0);
+                           const unsigned* probe = nullptr, unsigned probe_lo = 0, unsigned probe_hi = 0xffffffffu);
 size_t rvsr_dcn_bwdin_auto_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                                float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);
