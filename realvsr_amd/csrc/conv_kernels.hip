@@ -463,8 +463,7 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     else
         rc = launch_wgrad<1, 1, 64>(p, gy, gz, st);
     if (rc) return rc;
-    rvsr_launch_reduce(p.part, p.P, nw, grad_weight, accumulate, st);
-    if (grad_bias) rvsr_launch_reduce(p.bpart, p.P, (size_t)Co, grad_bias, accumulate, st);
+    rvsr_launch_reduce(p.part, p.P, nw, grad_weight, accumulate, st, p.bpart, (size_t)Co, grad_bias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad reduce launch: %s", hipGetErrorString(e));
     return RVSR_OK;

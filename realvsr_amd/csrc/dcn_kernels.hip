@@ -494,8 +494,7 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
             hipLaunchKernelGGL(dcn_bwd_weight_kernel<0>, dim3(p.P, gy, gz), dim3(RVSR_WG), lds, st, p);
         }
         // the reference accumulates into caller-zeroed gW/gBias (cpp:659-671) -> accumulate = 1
-        rvsr_launch_reduce(p.part, (int)Q, nw, gw, 1, st);
-        if (gb) rvsr_launch_reduce(p.bpart, (int)Q, (size_t)d.Co, gb, 1, st);
+        rvsr_launch_reduce(p.part, (int)Q, nw, gw, 1, st, p.bpart, (size_t)d.Co, gb);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward launch: %s", hipGetErrorString(e));

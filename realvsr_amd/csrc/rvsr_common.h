@@ -157,23 +157,32 @@ __device__ __forceinline__ float tcat_get(const TCat& t, int bidx, int c, int y,
 #define RVSR_ERR_WORKSPACE 4
 
 // dst[i] (+)= sum_q part[q][i], q < P: 64 elements per block, 4 thread groups stride over the
-// partials (fixed order -> run-to-run deterministic), combined through LDS.
-__global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst, int accumulate);
+// partials (fixed order -> run-to-run deterministic), combined through LDS.  A second segment (the bias partials of
+// the same weight-gradient call: [P][n2] -> dst2) rides in the same launch: blocks beyond ceil(n / 64) take it.
+__global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst,
+                                            const float* __restrict__ part2, size_t n2, float* dst2, int accumulate);
 #ifdef RVSR_DEFINE_REDUCE
-__global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst, int accumulate) {
+__global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int P, size_t n, float* dst,
+                                            const float* __restrict__ part2, size_t n2, float* dst2, int accumulate) {
     __shared__ float red[4][64];
     const int ex = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + ex;
-    float s0 = 0.f, s1 = 0.f;
+    const unsigned nb1 = (unsigned)((n + 63) / 64);
+    if (blockIdx.x >= nb1) {   // (uniform) second segment
+        part = part2; n = n2; dst = dst2;
+    }
+    const size_t i = (size_t)(blockIdx.x >= nb1 ? blockIdx.x - nb1 : blockIdx.x) * 64 + ex;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
         int q = grp;
-        for (; q + 4 < P; q += 8) {
+        for (; q + 12 < P; q += 16) {   // four loads in flight per thread
             s0 += part[(size_t)q * n + i];
             s1 += part[(size_t)(q + 4) * n + i];
+            s2 += part[(size_t)(q + 8) * n + i];
+            s3 += part[(size_t)(q + 12) * n + i];
         }
-        if (q < P) s0 += part[(size_t)q * n + i];
+        for (; q < P; q += 4) s0 += part[(size_t)q * n + i];
     }
-    red[grp][ex] = s0 + s1;
+    red[grp][ex] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && i < n) {
         const float s = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
@@ -181,8 +190,11 @@ __global__ void rvsr_reduce_partials_kernel(const float* __restrict__ part, int 
     }
 }
 #endif
-static inline void rvsr_launch_reduce(const float* part, int P, size_t n, float* dst, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(rvsr_reduce_partials_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, P, n, dst, accumulate);
+static inline void rvsr_launch_reduce(const float* part, int P, size_t n, float* dst, int accumulate, hipStream_t st,
+                                      const float* part2 = nullptr, size_t n2 = 0, float* dst2 = nullptr) {
+    if (!part2 || !dst2) n2 = 0;
+    hipLaunchKernelGGL(rvsr_reduce_partials_kernel, dim3((unsigned)((n + 63) / 64 + (n2 + 63) / 64)), dim3(256), 0, st, part, P, n, dst,
+                       part2, n2, dst2, accumulate);
 }
 
 #include <stdio.h>
