@@ -24,6 +24,8 @@ Extra objects on the line:
                   output pixel summed over the timed DCN launches / their HIP-event durations, vs the
                   8 TB/s HBM3E peak.  `traffic` is NOT measured in this run: it is the PMC measurement kept under
                   profiles/ rescaled to this run's launch size (`traffic_source` names the file).
+  roofline_conv -- the 3x3 nf->nf convolution (conv_fwd5_kernel) on all B*N frames, timed live after the timed region: MFMA
+                  work issued (3 bf16 passes per product) vs the 2.5 PFLOP/s dense bf16 peak, and the f32-equivalent rate.
   cpu_baseline -- the CPU oracle (oracle/edvr_oracle.py, kind "port") on ONE window of the same workload (B=1),
                   1 warm-up + best-of-3, timed on this box's host cores (rank 0, N=1 only).
 """
@@ -43,6 +45,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 MFMA peak (no sparsity)
+MFMA_F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32
 PMC_PROFILE = {64: 'profiles/r02_dcn_fwd_pmc.json', 128: 'profiles/r02_dcn_fwd_pmc_nf128.json'}
 
 
@@ -161,6 +165,34 @@ class _Proxy:
     @staticmethod
     def unwrap(RF):
         RF._lib._lib = _Proxy._real
+
+
+def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
+    """Second roofline object (outside the timed region): the 3x3 nf->nf convolution of the feature extractor on all B*N
+    frames -- the shape ~80 % of a step's GEMM work runs at -- timed live with HIP events on the launching stream.  `achieved`
+    counts the MFMA work actually issued (3 bf16 passes per f32 product in bf16x3 mode) against the dense bf16 peak;
+    `f32_equivalent` is the algorithmic 2*M*N*K rate."""
+    from realvsr_amd import functional as RF
+    conv = net.feature_extraction[0].conv1
+    x = torch.randn(frames, nf, H, W, device=conv.weight.device)
+    with torch.no_grad():
+        for _ in range(3):
+            RF.conv2d(x, conv, act=RF.ACT_RELU)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            RF.conv2d(x, conv, act=RF.ACT_RELU)
+        e.record()
+        torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    flop = 2.0 * frames * H * W * nf * nf * 9
+    passes = 3 if gemm_mode == 'bf16x3' else 1
+    peak = MFMA_BF16_PEAK_TFLOPS if gemm_mode == 'bf16x3' else MFMA_F32_PEAK_TFLOPS
+    ach = passes * flop / (ms * 1e-3) / 1e12
+    return {'kernel': 'conv_fwd5_kernel (+ its weight pre-pack): 3x3 %d->%d + ReLU on %d frames of %dx%d' % (nf, nf, frames, H, W),
+            'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'mfma_passes_per_product': passes, 'f32_equivalent': round(flop / (ms * 1e-3) / 1e12, 1),
+            'avg_launch_ms': round(ms, 4), 'traffic': None}
 
 
 def cpu_baseline(args):
@@ -360,6 +392,7 @@ def main():
                          'avg_launch_ms': round(kms / max(nl, 1), 4),
                          'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1))},
         }
+        line['roofline_conv'] = conv_roofline(model.netG, B * N, args.nf, H, W, gemm_mode)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

@@ -8,7 +8,7 @@ import re
 import shutil
 
 SRC, DST = 'gpurun_out/r02_profiles', 'profiles'
-for name in ['bench_default.json', 'offsets_1px.json', 'offsets_5px.json', 'bench_c3.json', 'bench_c3_1px.json', 'infer_c5.json',
+for name in ['bench_default.json', 'offsets_1px.json', 'offsets_2px.json', 'offsets_3px.json', 'offsets_5px.json', 'bench_c3.json', 'bench_c3_1px.json', 'infer_c5.json',
              'default_kernel_stats.csv', '1px_kernel_stats.csv', '5px_kernel_stats.csv', 'c3_kernel_stats.csv']:
     src = os.path.join(SRC, name)
     if not os.path.exists(src):

@@ -5,7 +5,7 @@
 O=gpurun_out/r02_profiles; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-for px in 1 5; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --offset-px $px > $O/offsets_${px}px.json 2>/dev/null; done
+for px in 1 2 3 5; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --offset-px $px > $O/offsets_${px}px.json 2>/dev/null; done
 python bench.py --nf 128 --nframes 7 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2>/dev/null
 python bench.py --nf 128 --nframes 7 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline --offset-px 1 > $O/bench_c3_1px.json 2>/dev/null
 python tools/infer_clip.py > $O/infer_c5.json 2>/dev/null
