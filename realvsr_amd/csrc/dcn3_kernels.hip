@@ -36,32 +36,30 @@ struct XTile16x40 {
     float v[5][4];
     bool inb0, inb4;
 };
-__device__ __forceinline__ void xtile16x40_load(XTile16x40& r, const DcnGeom& d, int b, int c0, int ty0, int tx0, int tid) {
-    const unsigned HW = (unsigned)(d.H * d.W);
-    const float* base = d.x + (size_t)b * d.C * HW;   // uniform; per-lane offsets below are 32-bit
+__device__ __forceinline__ void xtile16x40_load(XTile16x40& r, const DcnGeom& d, __amdgpu_buffer_rsrc_t x_rs, int c0, int ty0, int tx0, int tid) {
+    // x_rs: raw buffer view of this batch element's planes; plane offsets are uniform (SGPR), lane offsets 32-bit bytes
+    const unsigned HW4 = 4u * (unsigned)(d.H * d.W);
     {
         const int gy = ty0 + (tid >> 5), gx = tx0 + (tid & 31);
         r.inb0 = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
         const int gyc = gy < 0 ? 0 : (gy >= d.H ? d.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= d.W ? d.W - 1 : gx);
-        const unsigned off = (unsigned)(gyc * d.W + gxc);
+        const unsigned off = 4u * (unsigned)(gyc * d.W + gxc);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int c = c0 + 4 * j + e;
-                r.v[j][e] = base[(unsigned)(c < d.C ? c : d.C - 1) * HW + off];
+                const int c = c0 + 4 * j + e;   // (uniform)
+                r.v[j][e] = buf_load(x_rs, off, (unsigned)(c < d.C ? c : d.C - 1) * HW4);
             }
     }
     {
         const int gy = ty0 + ((tid >> 3) & 15), gx = tx0 + 32 + (tid & 7), q = tid >> 7;
         r.inb4 = gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
         const int gyc = gy < 0 ? 0 : (gy >= d.H ? d.H - 1 : gy), gxc = gx < 0 ? 0 : (gx >= d.W ? d.W - 1 : gx);
-        const unsigned off = (unsigned)(gyc * d.W + gxc);
+        const int qe = c0 + 4 * q < d.C ? q : 0;   // (C % 4 == 0: a quad exists entirely or not at all)
+        const unsigned off = 4u * (unsigned)(gyc * d.W + gxc) + (unsigned)(4 * qe) * HW4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c0 + 4 * q + e;
-            r.v[4][e] = base[(unsigned)(c < d.C ? c : d.C - 1) * HW + off];
-        }
+        for (int e = 0; e < 4; ++e) r.v[4][e] = buf_load(x_rs, off, (unsigned)(c0 + e) * HW4);
     }
 }
 // zero outside the image and beyond the last channel: the tap loop relies on it
@@ -125,6 +123,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
     // raw buffer views of this batch element's offset / mask planes (rvsr_launch_dcn_fwd3 checks that they span < 4 GB)
     const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs);
     const __amdgpu_buffer_rsrc_t msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
+    const __amdgpu_buffer_rsrc_t x_rs = buf_view(d.x + (size_t)b * d.C * HW), out_rs = buf_view(p.out + (size_t)b * d.Co * hw);
 
     f32x16 acc[MT];
 #pragma unroll
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
             }
             static_assert(TR == 16 && TC == 40 && NT == 512, "xtile16x40 is written for this tile");
             XTile16x40 xr;
-            xtile16x40_load(xr, d, b, c0, ty0, tx0, tid);
+            xtile16x40_load(xr, d, x_rs, c0, ty0, tx0, tid);
             TSTAMP(1 + 6 * chunk);
             TSTAMP(2 + 6 * chunk);
             xtile16x40_commit(xt, xr, d, c0, tid);
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
         // into "lane = channel, 4 consecutive pixels" (dword stores are store-issue-bound: 32 per lane, ~7.5 K cycles per tile)
         const int j = lo & 3, col4 = x0 + (lo & ~3);
         const bool col_ok = col4 < d.Wo;   // Wo % 4 == 0: the float4 is entirely inside or outside
-        const size_t pix4 = (size_t)oy * d.Wo + col4;
+        const unsigned lane_off = 4u * ((unsigned)(4 * hi + j) * (unsigned)hw + (unsigned)oy * d.Wo + col4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
                 float4 v = make_float4(r0 + bb, r1 + bb, r2 + bb, r3 + bb);
                 v.x = v.x > 0.f ? v.x : v.x * neg; v.y = v.y > 0.f ? v.y : v.y * neg;
                 v.z = v.z > 0.f ? v.z : v.z * neg; v.w = v.w > 0.f ? v.w : v.w * neg;
-                if (col_ok && o < d.Co) *reinterpret_cast<float4*>(p.out + ((size_t)b * d.Co + o) * hw + pix4) = v;
+                if (col_ok && o < d.Co) buf_store4(out_rs, lane_off, 4u * (unsigned)(mb * MP + mt * 32 + 8 * rg) * (unsigned)hw, v);
             }
         }
     } else {
@@ -309,8 +308,9 @@ static int launch_dcn_fwd3(const DcnFwdParams& p, const bf16x8* wpack, hipStream
 int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st) {
     const DcnGeom& d = p.d;
     if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
-    // 32-bit byte offsets into one batch element's offset planes (18 per deformable group): larger frames take dcn_fwd2
-    if ((size_t)(d.C / d.cpg) * 18 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 32)) return RVSR_ERR_UNSUPPORTED;
+    // 32-bit byte offsets into one batch element's x / offset / output planes: larger frames take dcn_fwd2
+    const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)(d.C > d.Co ? d.C : d.Co) ? (size_t)(d.C / d.cpg) * 18 : (size_t)(d.C > d.Co ? d.C : d.Co);
+    if (planes * d.H * d.W * sizeof(float) >= ((size_t)1 << 32)) return RVSR_ERR_UNSUPPORTED;
     const bf16x8* wp = (const bf16x8*)wpack;
     if (mt == 1) return launch_dcn_fwd3<1>(p, wp, st);
     if (mt == 2) return launch_dcn_fwd3<2>(p, wp, st);

@@ -247,6 +247,12 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned la
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, (int)lane_bytes, (int)uniform_bytes, 0);
 }
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes, float4 v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                     __builtin_bit_cast(unsigned, v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)lane_bytes, (int)uniform_bytes, 0);
+}
 __device__ __forceinline__ void buf_atomic_add(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rs, (int)lane_bytes, (int)uniform_bytes, 0);
 }
