@@ -871,8 +871,11 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             }
         }
     };
+    // Unconditional: beyond the last stage the loads repeat an earlier (tile, chunk) and the data is never used.  A uniform
+    // `if (q < Q)` around loads makes the compiler's s_waitcnt vmcnt(N) the minimum over both paths -- vmcnt(0) in
+    // mid-stage, i.e. the requests of tap 4 were waited for at tap 5 (a full L2/HBM round trip per stage and wave).
     auto issue_stage = [&](int q, int ch, int wsel, int xsel) {
-        if (q >= Q) return;
+        (void)q;
         issue_loads(itile, ch, wsel, xsel);
     };
 
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         const bf16x8* xs_lo = xs_hi + NX;
         const bf16x8* ws_hi = ws_base + buf * 2 * WVEC;
         const bf16x8* ws_lo = ws_hi + WVEC;
-        const bool pub = q + 1 < Q;   // stage q+1 exists: publish it into the other buffer during this stage
+        constexpr bool pub = true;    // publish stage q+1 into the other buffer during this stage (garbage after the last stage)
         bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
         auto fetch = [&](int tap, int slot) {
             const int dy = tap / KS, dx = tap % KS;
