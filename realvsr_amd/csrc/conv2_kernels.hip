@@ -676,6 +676,9 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     bf16x8* xs_base = reinterpret_cast<bf16x8*>(smem_raw);                // [2 buffers][hi|lo][NX]
     bf16x8* ws_base = xs_base + 2 * 2 * NX;                               // [2 buffers][hi|lo][WVEC]
     float* bias_base = reinterpret_cast<float*>(ws_base + 2 * 2 * WVEC);  // [4][MP]
+    // write-only slot: LDS stores of lanes without a valid destination land here, so that the publishing code has no
+    // divergent branch and shares a basic block (and the MFMA issue gaps) with the tap's matrix instructions
+    bf16x8* const sink = reinterpret_cast<bf16x8*>(bias_base + 4 * MP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const TView& va = p.in.a;
     const TView& vb = p.in.b;
@@ -840,17 +843,17 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                     const int s = 4 * (tid % NG) - 3 + e;
                     ok = ok && s >= 0 && s < IW;
                 }
-                if (ok) {
-                    xs_hi[dst] = h8;
-                    xs_lo[dst] = l8;
-                }
+                bf16x8* const dh = ok ? xs_hi + dst : sink;
+                bf16x8* const dl = ok ? xs_lo + dst : sink;
+                *dh = h8;
+                *dl = l8;
             }
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             if (wsel >= 0 && wsel != i) continue;
             const int e = tid + i * NTHR;
-            if (e < 2 * WVEC) ws[e] = wv[i];
+            *(e < 2 * WVEC ? ws + e : sink) = wv[i];
         }
     };
     // bias of tile k lives in slot k & 3: tiles k-1 .. k+1 can be alive at once when a tile is a single stage
@@ -1028,7 +1031,7 @@ static int launch_fwd2(const ConvFwdParams& p, hipStream_t st) {
 template <int MT>
 static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
     constexpr int NX = 2 * 18 * 34, WVEC = 9 * 2 * MT * 32;
-    const size_t lds = (size_t)16 * (2 * 2 * NX + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32;
+    const size_t lds = (size_t)16 * (2 * 2 * NX + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32 + 16;
     const TView& va = p.in.a;
     const TView& vb = p.in.b;
     const bool vec = va.mode == 0 && va.Ws % 4 == 0 && va.Wv == va.Ws &&
