@@ -715,6 +715,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     // the tile uses 34 (groups 0 and 9 contribute one pixel each).  All loads are unconditional (clamped addresses,
     // validity applied at the LDS write), see conv_fwd2_kernel.
     constexpr int NG = 10;
+    // buffer views (VEC staging): the packed weight image, and the current tile's batch element of each input / of act'
+    __amdgpu_buffer_rsrc_t w_rs = buf_view_2g(p.wpack), xa_rs = buf_view_2g(va.p), xb_rs = buf_view_2g(va.p), act_rs = buf_view_2g(va.p);
     constexpr int NIT = VEC ? 1 : (NX + NTHR - 1) / NTHR;  // input items per thread
     constexpr int NWV = (2 * WVEC + NTHR - 1) / NTHR;      // weight vectors per thread
     constexpr int NV = VEC ? 4 : 1;                        // pixels per item
@@ -724,6 +726,9 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (VEC) {
+                // byte offset of the 4-pixel group inside a channel plane, or an offset beyond every buffer view for a group
+                // outside the image / a thread without an item: raw buffer loads return 0 there, which IS the zero padding
+                // (no clamped address, no select per loaded value)
                 const bool live = tid < NOCT * IH * NG;
                 const int it = live ? tid : 0;
                 const int oc = it / (IH * NG), rem = it - oc * (IH * NG);
@@ -731,8 +736,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 const int gy = t.y0 - PAD + r, gx = t.x0 - 4 + 4 * g;
                 it_oc[i] = oc;
                 it_pos_ok[i] = live && gy >= 0 && gy < va.Hv && gx >= 0 && gx < va.Wv;
-                const int gyc = gy < 0 ? 0 : (gy >= va.Hv ? va.Hv - 1 : gy), gxc = gx < 0 ? 0 : (gx >= va.Wv ? va.Wv - 4 : gx);
-                it_sp[i] = gyc * va.Ws + gxc;
+                it_sp[i] = it_pos_ok[i] ? 4 * (gy * va.Ws + gx) : (int)0x80000000;
                 it_dst[i] = live ? (oc * IH + r) * IW + 4 * g - 3 : -100;  // LDS slot of the group's first pixel
             } else {
                 const int it_raw = tid + i * NTHR;
@@ -762,7 +766,46 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     bf16x8 wv[NWV];
     // slices: wsel < 0: all weight vectors, else only vector wsel (>= NWV: none); xsel < 0: all input loads, else
     // VEC: channels 4*xsel .. 4*xsel+3 of the item, non-VEC: item xsel (out-of-range: none)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
     auto issue_loads = [&](const Tile& t, int chunk, int wsel, int xsel) {
+        if (VEC) {
+            // Raw buffer addressing: weight image and the tile's batch element are buffer views, the (chunk, channel) part of an
+            // address is a uniform byte offset in an SGPR, the per-lane part is the 32-bit it_sp (+ the lane's octet).  The
+            // staging carries no 64-bit per-lane address arithmetic and no validity selects (launch_fwd5 checks the 4 GB spans).
+            const unsigned wbase = (unsigned)(((size_t)t.mb * nchunks + chunk) * 2 * WVEC) * 16u;
+#pragma unroll
+            for (int i = 0; i < NWV; ++i) {
+                if (wsel >= 0 && wsel != i) continue;
+                const int e = tid + i * NTHR;
+                const unsigned vo = e < 2 * WVEC ? (unsigned)tid * 16u : 0x80000000u;   // (only the last vector is ragged)
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)vo, (int)(wbase + (unsigned)i * NTHR * 16u), 0);
+                wv[i] = __builtin_bit_cast(bf16x8, w);
+            }
+            if (xsel >= 8) return;
+            const int c0 = chunk * 16;
+            const bool second = c0 >= C1;                 // (uniform: C1 % 16 == 0 whenever there is a second input)
+            const int Cb = second ? vb.C : va.C, cl0 = second ? c0 - C1 : c0;
+            const unsigned hw4 = 4u * (unsigned)(va.Hs * va.Ws);
+            const int lane_nch = Cb - cl0 - 8 * it_oc[0];   // channels of the lane's octet that exist (<= 0: none, >= 8: all)
+            const unsigned vo = (unsigned)it_sp[0] + (unsigned)(8 * it_oc[0]) * hw4;
+            nvalid[0] = 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (xsel >= 0 && (j >> 2) != xsel) continue;
+                const unsigned so = (unsigned)(cl0 + j) * hw4;
+                const unsigned vo_j = j < lane_nch ? vo : 0x80000000u;   // a channel beyond the tensor reads zeros, not memory
+                // (the whole vector is bit-cast at once: per-element extraction of the builtin's result is mis-folded by this
+                // hipcc into four copies of element 0)
+                const f32x4v q = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(second ? xb_rs : xa_rs, (int)vo_j, (int)so, 0));
+                vin[0][j][0] = q.x; vin[0][j][NV > 1 ? 1 : 0] = q.y; vin[0][j][NV > 2 ? 2 : 0] = q.z; vin[0][j][NV > 3 ? 3 : 0] = q.w;
+                if (ACT_IN) {
+                    const f32x4v a4 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(act_rs, (int)vo_j, (int)so, 0));
+                    ain[0][j][0] = a4.x; ain[0][j][NV > 1 ? 1 : 0] = a4.y; ain[0][j][NV > 2 ? 2 : 0] = a4.z; ain[0][j][NV > 3 ? 3 : 0] = a4.w;
+                }
+            }
+            return;
+        }
         const bf16x8* src = reinterpret_cast<const bf16x8*>(p.wpack) + ((size_t)t.mb * nchunks + chunk) * 2 * WVEC;
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -775,10 +818,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         const size_t hw = (size_t)va.Hs * va.Ws;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            if (!VEC && xsel >= 0 && xsel != i) continue;
+            if (xsel >= 0 && xsel != i) continue;
             const int cb = c0 + it_oc[i] * 8;
             const bool inb = it_pos_ok[i] && cb < Ctot;
-            if (VEC || va.mode != 2) {  // (uniform branch)
+            if (va.mode != 2) {  // (uniform branch)
                 const bool second = inb && cb >= C1;  // octets never straddle the two inputs (C1 % 8 == 0)
                 const float* bp = second ? vb.p : va.p;
                 const float* ap = va.act;
@@ -787,20 +830,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 nvalid[i] = inb ? (Cb - cl < 8 ? Cb - cl : 8) : 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (VEC && xsel >= 0 && (j >> 2) != xsel) continue;
                     const int cj = cl + j < Cb ? cl + j : Cb - 1;
                     const size_t idx = ((size_t)t.b * Cb + cj) * hw + it_sp[i];
-                    if (VEC) {
-                        const float4 q = *reinterpret_cast<const float4*>(bp + idx);
-                        vin[i][j][0] = q.x; vin[i][j][NV > 1 ? 1 : 0] = q.y; vin[i][j][NV > 2 ? 2 : 0] = q.z; vin[i][j][NV > 3 ? 3 : 0] = q.w;
-                        if (ACT_IN) {
-                            const float4 a = *reinterpret_cast<const float4*>(ap + idx);
-                            ain[i][j][0] = a.x; ain[i][j][NV > 1 ? 1 : 0] = a.y; ain[i][j][NV > 2 ? 2 : 0] = a.z; ain[i][j][NV > 3 ? 3 : 0] = a.w;
-                        }
-                    } else {
-                        vin[i][j][0] = bp[idx];
-                        if (ACT_IN) ain[i][j][0] = ap[idx];
-                    }
+                    vin[i][j][0] = bp[idx];
+                    if (ACT_IN) ain[i][j][0] = ap[idx];
                 }
             } else {  // mode 2: pixel-unshuffle view, virtual channel c -> stored (c>>2, 2y+((c>>1)&1), 2x+(c&1))
                 const int cbc = inb ? cb : 0;
@@ -823,9 +856,9 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (xsel >= 8 || (!VEC && xsel >= 0 && xsel != i)) continue;
-            unsigned vm[8];
+            unsigned vm[8];   // (VEC: the loads already returned zeros wherever the tile needs them)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vm[j] = j < nvalid[i] ? 0xffffffffu : 0u;
+            for (int j = 0; j < 8; ++j) vm[j] = VEC || j < nvalid[i] ? 0xffffffffu : 0u;
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 if (VEC && xsel >= 0 && xsel != e) continue;
@@ -868,6 +901,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         if (ch == 0) {
             itile = tile_of(k);
             item_geom(itile);
+            if (VEC) {
+                const size_t hw = (size_t)va.Hs * va.Ws;
+                xa_rs = buf_view_2g(va.p + (size_t)itile.b * va.C * hw);
+                if (vb.C) xb_rs = buf_view_2g(vb.p + (size_t)itile.b * vb.C * hw);
+                if (ACT_IN) act_rs = buf_view_2g(va.act + (size_t)itile.b * va.C * hw);
+            }
             if (tid < MP) {
                 const int o = itile.mb * MP + tid;
                 bias_base[(k & 3) * MP + tid] = (p.bias != nullptr && o < p.Co) ? p.bias[o] : 0.f;
@@ -1034,8 +1073,12 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
     const size_t lds = (size_t)16 * (2 * 2 * NX + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32 + 16;
     const TView& va = p.in.a;
     const TView& vb = p.in.b;
+    // VEC staging addresses one batch element of an input with 32-bit byte offsets (raw buffers) and selects the input per
+    // 16-channel chunk: planes of one element < 2 GB, a second input only behind a multiple of 16 channels
+    const size_t plane = sizeof(float) * (size_t)va.Hs * va.Ws;
     const bool vec = va.mode == 0 && va.Ws % 4 == 0 && va.Wv == va.Ws &&
-                     ((((uintptr_t)va.p) | ((uintptr_t)va.act) | ((uintptr_t)vb.p)) & 15) == 0;
+                     ((((uintptr_t)va.p) | ((uintptr_t)va.act) | ((uintptr_t)vb.p)) & 15) == 0 &&
+                     plane * (size_t)(va.C > vb.C ? va.C : vb.C) < ((size_t)1 << 31) && (vb.C == 0 || va.C % 16 == 0);
     auto k = va.act != nullptr ? (vec ? conv_fwd5_kernel<MT, true, true> : conv_fwd5_kernel<MT, true, false>)
                                : (vec ? conv_fwd5_kernel<MT, false, true> : conv_fwd5_kernel<MT, false, false>);
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd5: cannot reserve %zu B of LDS", lds);

@@ -241,6 +241,11 @@ static inline int set_lds(K kernel, size_t bytes) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_view(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xfffffffc, 0x00020000);
 }
+// 2 GB view: any lane offset with bit 31 set is out of range, and a raw buffer load returns 0 for it (the range check covers
+// the lane offset only, not the SGPR offset) -- used as "this lane reads zero padding"
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_view_2g(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x80000000u, 0x00020000);
+}
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_bytes, (int)uniform_bytes, 0));
 }
