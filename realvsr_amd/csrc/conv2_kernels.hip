@@ -666,7 +666,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd3_kernel(const ConvFwdParams p
 // SIMD get roughly one issue slot per MFMA (~18 cycles per instruction: conv_fwd3's staging slot, and a variant with
 // dedicated staging waves ran 2x slower).  Registers of stage q+1 are published to LDS during taps 0-3 (inputs) and
 // 4-8 (weights) of stage q and refilled at once with the loads of stage q+2, so the staging registers are not doubled.
-template <int MT, bool ACT_IN, bool VEC>
+// VEC: 0 = scalar staging (any view), 1 = vector staging of a plain view, 2 = vector staging of a pixel-unshuffle view
+template <int MT, bool ACT_IN, int VEC>
 __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p) {
     constexpr int KS = 3, T = 9, PAD = 1, NW = 8, TH = 2 * NW, TW = 32, NTHR = NW * 64;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 const int gy = t.y0 - PAD + r, gx = t.x0 - 4 + 4 * g;
                 it_oc[i] = oc;
                 it_pos_ok[i] = live && gy >= 0 && gy < va.Hv && gx >= 0 && gx < va.Wv;
-                it_sp[i] = it_pos_ok[i] ? 4 * (gy * va.Ws + gx) : (int)0x80000000;
+                it_sp[i] = it_pos_ok[i] ? (VEC == 2 ? 8 * (gy * va.Ws + gx) : 4 * (gy * va.Ws + gx)) : (int)0x80000000;   // (mode 2: stored row 2 gy, column 2 gx)
                 it_dst[i] = live ? (oc * IH + r) * IW + 4 * g - 3 : -100;  // LDS slot of the group's first pixel
             } else {
                 const int it_raw = tid + i * NTHR;
@@ -788,8 +789,31 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             const int Cb = second ? vb.C : va.C, cl0 = second ? c0 - C1 : c0;
             const unsigned hw4 = 4u * (unsigned)(va.Hs * va.Ws);
             const int lane_nch = Cb - cl0 - 8 * it_oc[0];   // channels of the lane's octet that exist (<= 0: none, >= 8: all)
-            const unsigned vo = (unsigned)it_sp[0] + (unsigned)(8 * it_oc[0]) * hw4;
             nvalid[0] = 8;
+            if (VEC == 2) {
+                // pixel-unshuffle view (the data gradient of conv + PixelShuffle): virtual channel c of pixel (y, x) is stored
+                // channel c >> 2 at (2y + ((c >> 1) & 1), 2x + (c & 1)).  The item's 8 channels x 4 pixels are 2 stored
+                // channels x 2 stored rows x 8 stored columns = eight 16-byte loads (csl, sy, half); element e of a load is
+                // channel 4 csl + 2 sy + (e & 1) of pixel 2 half + (e >> 1) -- a compile-time renaming of registers.
+                const unsigned row4 = 4u * (unsigned)va.Ws, pl4 = row4 * (unsigned)va.Hs;   // stored row / plane in bytes
+                const unsigned vo = (unsigned)it_sp[0] + (unsigned)(2 * it_oc[0]) * pl4;
+                const unsigned vo_l = lane_nch > 0 ? vo : 0x80000000u;   // (virtual channel counts are multiples of 4 here)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int csl = l >> 2, sy = (l >> 1) & 1, half = l & 1;
+                    if (xsel >= 0 && csl != xsel) continue;
+                    const unsigned so = (unsigned)((cl0 >> 2) + csl) * pl4 + (unsigned)sy * row4 + 16u * half;
+                    const f32x4v q = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xa_rs, (int)vo_l, (int)so, 0));
+                    const int j0 = 4 * csl + 2 * sy, e0 = (2 * half) & (NV - 1), e1 = (2 * half + 1) & (NV - 1);
+                    vin[0][j0][e0] = q.x; vin[0][j0 + 1][e0] = q.y; vin[0][j0][e1] = q.z; vin[0][j0 + 1][e1] = q.w;
+                    if (ACT_IN) {
+                        const f32x4v a4 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(act_rs, (int)vo_l, (int)so, 0));
+                        ain[0][j0][e0] = a4.x; ain[0][j0 + 1][e0] = a4.y; ain[0][j0][e1] = a4.z; ain[0][j0 + 1][e1] = a4.w;
+                    }
+                }
+                return;
+            }
+            const unsigned vo = (unsigned)it_sp[0] + (unsigned)(8 * it_oc[0]) * hw4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (xsel >= 0 && (j >> 2) != xsel) continue;
@@ -903,9 +927,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             item_geom(itile);
             if (VEC) {
                 const size_t hw = (size_t)va.Hs * va.Ws;
-                xa_rs = buf_view_2g(va.p + (size_t)itile.b * va.C * hw);
+                const size_t img_a = (size_t)(VEC == 2 ? va.C >> 2 : va.C) * hw;   // stored elements per batch element
+                xa_rs = buf_view_2g(va.p + (size_t)itile.b * img_a);
                 if (vb.C) xb_rs = buf_view_2g(vb.p + (size_t)itile.b * vb.C * hw);
-                if (ACT_IN) act_rs = buf_view_2g(va.act + (size_t)itile.b * va.C * hw);
+                if (ACT_IN) act_rs = buf_view_2g(va.act + (size_t)itile.b * img_a);
             }
             if (tid < MP) {
                 const int o = itile.mb * MP + tid;
@@ -1076,11 +1101,16 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
     // VEC staging addresses one batch element of an input with 32-bit byte offsets (raw buffers) and selects the input per
     // 16-channel chunk: planes of one element < 2 GB, a second input only behind a multiple of 16 channels
     const size_t plane = sizeof(float) * (size_t)va.Hs * va.Ws;
-    const bool vec = va.mode == 0 && va.Ws % 4 == 0 && va.Wv == va.Ws &&
-                     ((((uintptr_t)va.p) | ((uintptr_t)va.act) | ((uintptr_t)vb.p)) & 15) == 0 &&
-                     plane * (size_t)(va.C > vb.C ? va.C : vb.C) < ((size_t)1 << 31) && (vb.C == 0 || va.C % 16 == 0);
-    auto k = va.act != nullptr ? (vec ? conv_fwd5_kernel<MT, true, true> : conv_fwd5_kernel<MT, true, false>)
-                               : (vec ? conv_fwd5_kernel<MT, false, true> : conv_fwd5_kernel<MT, false, false>);
+    const bool al16 = ((((uintptr_t)va.p) | ((uintptr_t)va.act) | ((uintptr_t)vb.p)) & 15) == 0;
+    int vec = 0;
+    if (va.mode == 0 && va.Ws % 4 == 0 && va.Wv == va.Ws && al16 &&
+        plane * (size_t)(va.C > vb.C ? va.C : vb.C) < ((size_t)1 << 31) && (vb.C == 0 || va.C % 16 == 0))
+        vec = 1;
+    else if (va.mode == 2 && vb.C == 0 && va.C % 16 == 0 && va.Wv % 4 == 0 && va.Ws == 2 * va.Wv && va.Hs == 2 * va.Hv && al16 &&
+             plane * (size_t)(va.C >> 2) < ((size_t)1 << 31))
+        vec = 2;
+    auto k = va.act != nullptr ? (vec == 2 ? conv_fwd5_kernel<MT, true, 2> : vec ? conv_fwd5_kernel<MT, true, 1> : conv_fwd5_kernel<MT, true, 0>)
+                               : (vec == 2 ? conv_fwd5_kernel<MT, false, 2> : vec ? conv_fwd5_kernel<MT, false, 1> : conv_fwd5_kernel<MT, false, 0>);
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd5: cannot reserve %zu B of LDS", lds);
     const int nty = (p.Hout + 15) / 16;
     const long items = (long)p.ntx * nty * ((p.Co + MT * 32 - 1) / (MT * 32)) * p.B;
