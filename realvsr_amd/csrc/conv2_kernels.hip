@@ -1267,13 +1267,16 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     constexpr int NGV = GMODE == 0 ? 2 : 4; // float4 per G item (8 virtual px; pixel-shuffled storage holds 16 floats)
     constexpr int NXI = 4;                  // X items per thread: 64 c x 6 rows x 5 octets = 1920 / 512 -> 3.75
     float4 gv[NGI][NGV], sv[ACT ? NGI : 1][NGV], xv[NXI][2];
-    unsigned gok = 0, xok = 0;              // bit (i * 4 + k): float4 k of item i is inside the image
     float bacc[NGI] = {0.f, 0.f};           // bias-gradient partial sums of this thread's two G items
 
-    // per-thread item geometry is tile-independent: decode it once (the divisions / 64-bit products used to cost more
-    // than the loads themselves: ~5.5 K cycles to issue 20 loads)
+    // Raw buffer addressing (see conv_fwd5_kernel): a thread's item has a tile-independent 32-bit byte offset inside one image of
+    // its tensor, the tile contributes a uniform byte offset (SGPR), and a float4 outside the image -- or an item without a
+    // channel -- gets an offset beyond the 2 GB view, for which the load returns zeros: no clamped addresses, no validity flags,
+    // no selects on the way to LDS.  (The 64-bit address chains and selects were ~14 vector instructions per load, inside the
+    // MFMA phase.)  rvsr_launch_conv_wgrad2 checks the spans and that a second input starts on a multiple of 64 channels.
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned g_vo[NGI], x_vo[NXI];
     int g_row[NGI], g_gx8[NGI], g_o[NGI], g_lds[NGI];
-    unsigned g_const[NGI];
 #pragma unroll
     for (int i = 0; i < NGI; ++i) {
         const int it = tid + i * WG2_THREADS;
@@ -1282,13 +1285,13 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         g_gx8[i] = 8 * q;
         g_o[i] = mb * 64 + ol;
         g_lds[i] = ol * WG2_GP + row * 64 + q * 16;
-        const int o = g_o[i] < p.Co ? g_o[i] : 0;
-        g_const[i] = GMODE == 0 ? (unsigned)((o * H + row) * W + 8 * q)
-                                : (unsigned)((((o >> 2) * 2 * H) + 2 * row + ((o >> 1) & 1)) * (2 * W) + 16 * q);
+        const int o = g_o[i];
+        g_vo[i] = o >= p.Co ? OOB
+                : 4u * (GMODE == 0 ? (unsigned)((o * H + row) * W + 8 * q)
+                                   : (unsigned)((((o >> 2) * 2 * H) + 2 * row + ((o >> 1) & 1)) * (2 * W) + 16 * q));
     }
+    const bool sec = c0 >= C1;              // (uniform) this workgroup's 64 channels come from the second input
     int x_row[NXI], x_gx[NXI], x_lds[NXI];
-    unsigned x_const[NXI];
-    bool x_live[NXI], x_sec[NXI];
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
         const int it_raw = tid + i * WG2_THREADS;
@@ -1297,23 +1300,19 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         const int cl = it / 30, rem = it - cl * 30;
         const int row = rem / 5, q = rem - row * 5;
         const int c = c0 + cl;
-        x_live[i] = live && c < Ctot;
-        x_sec[i] = x_live[i] && c >= C1;
         x_row[i] = row - 1;
         x_gx[i] = 8 * q - 4;
         x_lds[i] = live ? cl * WG2_XP + row * 80 + q * 16 : -1;
-        const int cc = x_live[i] ? (x_sec[i] ? c - C1 : c) : 0;
-        x_const[i] = (unsigned)(cc * H * W);
+        // relative to a view that starts one row and four pixels BEFORE the image (so that row -1 / column -4 are offset >= 0)
+        x_vo[i] = live && c < Ctot ? 4u * (unsigned)(((sec ? c - C1 : c) * H + row) * W + 8 * q) : OOB;
     }
-    const size_t img_g = GMODE == 0 ? (size_t)p.Co * H * W : (size_t)p.Co * H * W;  // elements per image of G (same count either way)
+    const size_t img_g = (size_t)p.Co * H * W;  // elements per image of G (same count for the pixel-shuffled storage)
     const size_t img_x1 = (size_t)C1 * H * W, img_x2 = (size_t)(Ctot - C1) * H * W;
 
     // `part` < 0: everything at once (prologue).  Otherwise part 0..7 = one eighth of the tile's loads: the main loop
     // issues one part per k-step of the MFMA phase so the requests trickle out under the matrix work instead of as one
     // burst in front of it (the burst took ~5.5 K cycles to issue: the memory pipeline back-pressures).
     // parts 0-3: X item `part`; parts 4, 5: G item 0, 1; parts 6, 7: nothing.
-    // tile -> (image, row, column) once per tile: issue_loads runs eight times per tile (a slice per MFMA k-step) and two
-    // run-time divisions per call were ~400 vector instructions per tile inside the MFMA loop
     struct TilePos { int b, y0, x0; };
     auto tile_pos = [&](int tile) {
         TilePos t;
@@ -1324,54 +1323,49 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         t.x0 = (trem - ty * p.ntx) * 32;
         return t;
     };
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so) {
+        const f32x4v q = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, (int)so, 0));
+        return make_float4(q.x, q.y, q.z, q.w);
+    };
     auto issue_loads = [&](const TilePos& tp, int part) {
-        const int b = tp.b, y0 = tp.y0, x0 = tp.x0;
-        if (part < 0 || part == 4) gok = 0;
-        if (part <= 0) xok = 0;
-        const float* gimg = p.g.p + (size_t)b * img_g;
-        const float* simg = ACT ? p.g.act + (size_t)b * img_g : nullptr;
+        const int b = tp.b;
+        int y0 = tp.y0, x0 = tp.x0;
+        // opaque per call: otherwise the (now cheap) lane offsets of all eight slices are computed once per tile, ahead of the
+        // k-step loop, and live across it (56 spilled registers in the <ACT, pixel-shuffle> instantiation)
+        asm volatile("" : "+s"(y0), "+s"(x0));
+        if (part < 0 || part >= 4) {
+            const __amdgpu_buffer_rsrc_t g_rs = buf_view_2g(p.g.p + (size_t)b * img_g);
+            const __amdgpu_buffer_rsrc_t s_rs = buf_view_2g(ACT ? p.g.act + (size_t)b * img_g : p.g.p);
+            const unsigned so = GMODE == 0 ? 4u * (unsigned)(y0 * W + x0) : 4u * (unsigned)(2 * y0 * 2 * W + 2 * x0);
 #pragma unroll
-        for (int i = 0; i < NGI; ++i) {
-            if (part >= 0 && part != 4 + i) continue;
-            const int gy = y0 + g_row[i], gx = x0 + g_gx8[i];
-            const bool ok = g_o[i] < p.Co && gy < H;
-            if (GMODE == 0) {
-                const unsigned base = g_const[i] + (unsigned)(y0 * W + x0);
+            for (int i = 0; i < NGI; ++i) {
+                if (part >= 0 && part != 4 + i) continue;
+                const int gx = x0 + g_gx8[i];
+                const bool ok = y0 + g_row[i] < H;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bool okk = ok && gx + 4 * kk < W;
-                    const unsigned idx = okk ? base + 4 * kk : 0;
-                    gv[i][kk] = *reinterpret_cast<const float4*>(gimg + idx);
-                    if (ACT) sv[i][kk] = *reinterpret_cast<const float4*>(simg + idx);
-                    gok |= (okk ? 1u : 0u) << (i * 4 + kk);
-                }
-            } else {
-                const unsigned base = g_const[i] + (unsigned)(2 * y0 * 2 * W + 2 * x0);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const bool okk = ok && gx + 2 * kk < W;
-                    const unsigned idx = okk ? base + 4 * kk : 0;
-                    gv[i][kk] = *reinterpret_cast<const float4*>(gimg + idx);
-                    if (ACT) sv[i][kk] = *reinterpret_cast<const float4*>(simg + idx);
-                    gok |= (okk ? 1u : 0u) << (i * 4 + kk);
+                for (int kk = 0; kk < NGV; ++kk) {
+                    const bool okk = ok && gx + (GMODE == 0 ? 4 : 2) * kk < W;
+                    const unsigned vo = okk ? g_vo[i] + 16u * kk : OOB;
+                    gv[i][kk] = ld4(g_rs, vo, so);
+                    if (ACT) sv[i][kk] = ld4(s_rs, vo, so);
                 }
             }
         }
-        const float* x1img = p.x.a.p + (size_t)b * img_x1;
-        const float* x2img = p.x.b.p != nullptr ? p.x.b.p + (size_t)b * img_x2 : x1img;
+        if (part < 0 || part < 4) {
+            const float* ximg = sec ? p.x.b.p + (size_t)b * img_x2 : p.x.a.p + (size_t)b * img_x1;
+            const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(ximg - (W + 4));
+            const unsigned so = 4u * (unsigned)(y0 * W + x0);
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            if (part >= 0 && part != i) continue;
-            const int gy = y0 + x_row[i], gx = x0 + x_gx[i];
-            const bool ok = x_live[i] && gy >= 0 && gy < H;
-            const float* src = x_sec[i] ? x2img : x1img;
-            const unsigned base = x_const[i] + (unsigned)((ok ? gy : 0) * W);
+            for (int i = 0; i < NXI; ++i) {
+                if (part >= 0 && part != i) continue;
+                const int gy = y0 + x_row[i], gx = x0 + x_gx[i];
+                const bool ok = gy >= 0 && gy < H;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int gxx = gx + 4 * kk;
-                const bool okk = ok && gxx >= 0 && gxx < W;
-                xv[i][kk] = *reinterpret_cast<const float4*>(src + (okk ? base + gxx : 0));
-                xok |= (okk ? 1u : 0u) << (i * 4 + kk);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int gxx = gx + 4 * kk;
+                    xv[i][kk] = ld4(x_rs, ok && gxx >= 0 && gxx < W ? x_vo[i] + 16u * kk : OOB, so);
+                }
             }
         }
     };
@@ -1384,21 +1378,18 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             if (GMODE == 0) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const bool okk = (gok >> (i * 4 + k)) & 1;
                     float4 a = gv[i][k];
                     if (ACT) {
                         const float4 s_ = sv[i][k];
                         a.x *= s_.x > 0.f ? 1.f : p.g.slope; a.y *= s_.y > 0.f ? 1.f : p.g.slope;
                         a.z *= s_.z > 0.f ? 1.f : p.g.slope; a.w *= s_.w > 0.f ? 1.f : p.g.slope;
                     }
-                    v[4 * k + 0] = okk ? a.x : 0.f; v[4 * k + 1] = okk ? a.y : 0.f;
-                    v[4 * k + 2] = okk ? a.z : 0.f; v[4 * k + 3] = okk ? a.w : 0.f;
+                    v[4 * k + 0] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
                 }
             } else {
                 const int sx = (mb * 64 + ol) & 1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool okk = (gok >> (i * 4 + k)) & 1;
                     const float4 a = gv[i][k];
                     float e0 = sx ? a.y : a.x, e1 = sx ? a.w : a.z;
                     if (ACT) {
@@ -1406,8 +1397,8 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                         e0 *= (sx ? s_.y : s_.x) > 0.f ? 1.f : p.g.slope;
                         e1 *= (sx ? s_.w : s_.z) > 0.f ? 1.f : p.g.slope;
                     }
-                    v[2 * k] = okk ? e0 : 0.f;
-                    v[2 * k + 1] = okk ? e1 : 0.f;
+                    v[2 * k] = e0;
+                    v[2 * k + 1] = e1;
                 }
             }
             // bias gradient: a G item's output channel does not depend on the tile, so every thread keeps its own
@@ -1425,10 +1416,8 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             float v[8];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const bool okk = (xok >> (i * 4 + k)) & 1;
                 const float4 a = xv[i][k];
-                v[4 * k + 0] = okk ? a.x : 0.f; v[4 * k + 1] = okk ? a.y : 0.f;
-                v[4 * k + 2] = okk ? a.z : 0.f; v[4 * k + 3] = okk ? a.w : 0.f;
+                v[4 * k + 0] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
             }
             bf16x8 h8, l8;
             split8(v, h8, l8);
@@ -1456,7 +1445,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         if (m_live) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                if (more) issue_loads(next_pos, ks);
+                if (GMODE != 2 || more) issue_loads(next_pos, ks);   // (unconditional for the plain view: after the last tile it re-reads that tile)
                 __builtin_amdgcn_sched_barrier(0);
                 const int row = ks >> 1, cb = (ks & 1) * 16 + 8 * hi;  // this lane's 8 pixels: row, cols cb..cb+7
                 const int goff = (m * 32 + lo) * WG2_GP + row * 64 + cb * 2;

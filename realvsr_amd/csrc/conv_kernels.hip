@@ -447,7 +447,11 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool aligned16 = ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)gout) | ((uintptr_t)gact)) & 15) == 0;
-    if (rvsr_g_gemm_mode == 0 && ksize == 3 && stride == 1 && (Wout % 4) == 0 && aligned16)
+    // conv_wgrad2 addresses one image of each tensor with 32-bit byte offsets (raw buffers, < 2 GB) and picks the input per
+    // 64-channel block: a second input has to start on a multiple of 64 channels
+    const size_t img_max = sizeof(float) * (size_t)Hout * Wout * (size_t)(Co > Ctot ? Co : Ctot);
+    if (rvsr_g_gemm_mode == 0 && ksize == 3 && stride == 1 && (Wout % 4) == 0 && aligned16 && img_max < ((size_t)1 << 31) &&
+        (C2 == 0 || C1 % 64 == 0))
         rc = rvsr_launch_conv_wgrad2(p, gy, gz, st);
     else if (rvsr_g_gemm_mode == 0 && ksize == 1 && g_mode == 0 && ((Hout * Wout) % 8) == 0 && aligned16)
         rc = rvsr_launch_conv_wgrad1x1(p, gy, gz, st);
