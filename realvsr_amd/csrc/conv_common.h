@@ -89,3 +89,6 @@ extern int rvsr_g_gemm_mode;
 int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
 int rvsr_launch_conv_wgrad1x1(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
 int rvsr_launch_conv_wgrad_s2(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
+// conv_thin_kernels.hip: 3x3 / stride-1 layers with <= 4 output channels on the vector ALU (exact f32)
+int rvsr_conv_wgrad_thin_P(int B, int Hout, int Wout);
+int rvsr_launch_conv_wgrad_thin(const ConvWgradParams& p, hipStream_t st);

@@ -394,6 +394,10 @@ extern "C" size_t rvsr_conv2d_wgrad_workspace_bytes(int C1, int C2, int Co, int 
         const size_t P2 = wgrad_s2_P(B, Hout, Wout, gy, (C1 + C2 + 63) / 64);
         if (P2 > P) P = P2;
     }
+    if (ksize == 3 && stride == 1 && Co <= 4) {  // the thin-layer kernel keeps one partial per workgroup of its own grid
+        const size_t P3 = rvsr_conv_wgrad_thin_P(B, Hout, Wout);
+        if (P3 > P) P = P3;
+    }
     return sizeof(float) * P * ((size_t)Co * (C1 + C2) * ksize * ksize + Co);
 }
 
@@ -447,6 +451,18 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool aligned16 = ((((uintptr_t)x1) | ((uintptr_t)x2) | ((uintptr_t)gout) | ((uintptr_t)gact)) & 15) == 0;
+    if (ksize == 3 && stride == 1 && Co <= 4 && C2 == 0 && C1 % 16 == 0 && g_mode == 0 && (Wout % 4) == 0 && aligned16 &&
+        sizeof(float) * (size_t)Hout * Wout * (size_t)C1 < ((size_t)1 << 31)) {
+        // thin layer (conv_last): vector-ALU kernel, exact f32 in both GEMM modes
+        p.P = rvsr_conv_wgrad_thin_P(B, Hout, Wout);
+        p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;
+        rc = rvsr_launch_conv_wgrad_thin(p, st);
+        if (rc) return rc;
+        rvsr_launch_reduce(p.part, p.P, nw, grad_weight, accumulate, st, p.bpart, (size_t)Co, grad_bias);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad reduce launch: %s", hipGetErrorString(e2));
+        return RVSR_OK;
+    }
     // conv_wgrad2 addresses one image of each tensor with 32-bit byte offsets (raw buffers, < 2 GB) and picks the input per
     // 64-channel block: a second input has to start on a multiple of 64 channels
     const size_t img_max = sizeof(float) * (size_t)Hout * Wout * (size_t)(Co > Ctot ? Co : Ctot);

@@ -33,6 +33,8 @@ CASES = [
     (16, 0, 24, 3, 2, 'none', False, False, 1, 18, 32),      # same, odd output height, Co/C not multiples of 32
     (128, 0, 128, 3, 1, 'relu', False, False, 1, 12, 36),
     (64, 0, 64, 3, 1, 'lrelu', True, False, 1, 16, 24),   # act + residual (sAtt_3 pattern)
+    (32, 0, 4, 3, 1, 'lrelu', False, False, 2, 10, 72),    # thin layer (Co <= 4) on the vector-ALU weight-gradient kernel: act', ragged tile
+    (16, 0, 1, 3, 1, 'none', False, False, 3, 7, 132),      # thin layer, one output channel, three column tiles
 ]
 
 
