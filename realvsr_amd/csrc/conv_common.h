@@ -92,3 +92,5 @@ int rvsr_launch_conv_wgrad_s2(const ConvWgradParams& p, int gy, int gz, hipStrea
 // conv_thin_kernels.hip: 3x3 / stride-1 layers with <= 4 output channels on the vector ALU (exact f32)
 int rvsr_conv_wgrad_thin_P(int B, int Hout, int Wout);
 int rvsr_launch_conv_wgrad_thin(const ConvWgradParams& p, hipStream_t st);
+bool rvsr_conv_fwd_thin_ok(const ConvFwdParams& p, int ksize, int stride);
+int rvsr_launch_conv_fwd_thin(const ConvFwdParams& p, hipStream_t st);

@@ -159,3 +159,125 @@ int rvsr_launch_conv_wgrad_thin(const ConvWgradParams& p, hipStream_t st) {
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad_thin launch: %s", hipGetErrorString(e));
     return RVSR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Forward:  out[b,o,y,x] = act(bias[o] + sum_{c,tap} W[o][c][tap] * X[b,c,y+dy-1,x+dx-1]) (+ residual),  Co <= 4, C % 8 == 0.
+// conv_last at the HR resolution on conv_fwd5_kernel<1>: 1.05 ms per call (a 32-row M tile with 3 live rows, bf16 hi/lo staging of
+// 64 channels) against ~0.4 ms of HBM time.  Here one workgroup computes an 8 x 128 pixel tile, a thread four consecutive pixels
+// of one row for all output channels; the input passes through LDS as f32 eight channels at a time, the weights sit in LDS as
+// [c][tap][o0..o3] so that one broadcast 16-byte read feeds two packed FMAs per pixel.
+#define THIN_FW 136          // staged columns per row: image columns x0-4 .. x0+131
+#define THIN_FPL (10 * THIN_FW)
+__global__ __launch_bounds__(THIN_T, 2) void conv_fwd_thin_kernel(const ConvFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* const xs = fsm;                    // [8 ch][10 rows][136 cols]
+    float* const ws = fsm + 8 * THIN_FPL;     // [C][9][4]
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const TView& va = p.in.a;
+    const int tid = threadIdx.x, r = tid >> 5, col4 = (tid & 31) * 4;
+    const int C = va.C, H = p.Hout, W = p.Wout, Co = p.Co;
+    const unsigned HW4 = 4u * (unsigned)(H * W);
+    const int ntx = (W + 127) / 128, nty = (H + 7) / 8;
+    const int b = blockIdx.x / (nty * ntx), trem = blockIdx.x - b * (nty * ntx), ty = trem / ntx;
+    const int y0 = ty * 8, x0 = (trem - ty * ntx) * 128;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // weights -> LDS, [c][tap][o] with zeros for o >= Co
+    for (int e = tid; e < C * 9 * 4; e += THIN_T) {
+        const int o = e & 3, ct = e >> 2;   // ct = c * 9 + tap
+        ws[e] = o < Co ? p.w[(size_t)o * C * 9 + ct] : 0.f;
+    }
+    // staging items of this thread (8 ch x 10 rows x 34 float4 = 2720 = 10.6 per thread)
+    unsigned x_vo[11];
+    int x_lds[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int it = tid + i * THIN_T;
+        const bool live = it < 8 * 10 * 34;
+        const int c = live ? it / 340 : 0, rem = live ? it - c * 340 : 0, row = rem / 34, q = rem - row * 34;
+        const int gy = y0 + row - 1, gx = x0 + 4 * q - 4;
+        const bool ok = live && gy >= 0 && gy < H && gx >= 0 && gx < W;   // (W % 4 == 0)
+        x_lds[i] = live ? c * THIN_FPL + row * THIN_FW + 4 * q : -1;
+        x_vo[i] = ok ? (unsigned)c * HW4 + 4u * (unsigned)(row * W + 4 * q) : OOB;   // view starts one row + 4 px before the image
+    }
+    const unsigned so = 4u * (unsigned)(y0 * W + x0);
+
+    f32x2v acc[4][2];
+    {
+        const float b0 = p.bias && Co > 0 ? p.bias[0] : 0.f, b1 = p.bias && Co > 1 ? p.bias[1] : 0.f;
+        const float b2 = p.bias && Co > 2 ? p.bias[2] : 0.f, b3 = p.bias && Co > 3 ? p.bias[3] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j][0] = f32x2v{b0, b1}; acc[j][1] = f32x2v{b2, b3}; }
+    }
+    for (int cg = 0; cg < C / 8; ++cg) {
+        const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(va.p + ((size_t)b * C + cg * 8) * H * W - (W + 4));
+        f32x4v xv[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i)
+            xv[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)x_vo[i], (int)so, 0));
+        __syncthreads();   // readers of the previous group are done (and, the first time, ws is complete)
+#pragma unroll
+        for (int i = 0; i < 11; ++i)
+            if (x_lds[i] >= 0) *reinterpret_cast<f32x4v*>(xs + x_lds[i]) = xv[i];
+        __syncthreads();
+#pragma unroll 2
+        for (int c = 0; c < 8; ++c) {
+            const float* wc = ws + (cg * 8 + c) * 36;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* xrow = xs + c * THIN_FPL + (r + dy) * THIN_FW + col4;   // staged column col4 = image column x0+col4-4
+                const f32x4v xa = *reinterpret_cast<const f32x4v*>(xrow), xb = *reinterpret_cast<const f32x4v*>(xrow + 4);
+                const float x6[6] = {xa.w, xb.x, xb.y, xb.z, xb.w, xrow[8]};   // image columns x0+col4-1 .. x0+col4+4
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const f32x4v w4 = *reinterpret_cast<const f32x4v*>(wc + (dy * 3 + dx) * 4);
+                    const f32x2v w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j][0] += w01 * x6[j + dx];
+                        acc[j][1] += w23 * x6[j + dx];
+                    }
+                }
+            }
+        }
+    }
+    // ---- epilogue: activation, residual, one 16-byte store per output channel
+    const int oy = y0 + r, ox = x0 + col4;
+    if (oy >= H || ox >= W) return;
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o >= Co) break;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = o == 0 ? acc[j][0].x : (o == 1 ? acc[j][0].y : (o == 2 ? acc[j][1].x : acc[j][1].y));
+            v[j] = a > 0.f ? a : a * neg;
+        }
+        const size_t idx = (((size_t)b * Co + o) * H + oy) * W + ox;
+        if (p.res != nullptr) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.res + idx);
+            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        *reinterpret_cast<float4*>(p.out1 + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// 3x3 / stride 1 / plain view / single input and output / no act' / f32 weights in the reference layout
+bool rvsr_conv_fwd_thin_ok(const ConvFwdParams& p, int ksize, int stride) {
+    const TView& va = p.in.a;
+    return ksize == 3 && stride == 1 && p.Co <= 4 && p.in.b.C == 0 && va.C % 8 == 0 && va.mode == 0 && va.act == nullptr &&
+           p.out2 == nullptr && !p.ps && p.w_mode == 0 && p.Wout % 4 == 0 && va.Ws == p.Wout && va.Hs == p.Hout &&
+           ((((uintptr_t)va.p) | ((uintptr_t)p.out1) | ((uintptr_t)p.res)) & 15) == 0 &&
+           sizeof(float) * (size_t)p.Hout * p.Wout * (size_t)va.C < ((size_t)1 << 31) && va.C <= 256;
+}
+int rvsr_launch_conv_fwd_thin(const ConvFwdParams& p, hipStream_t st) {
+    const size_t lds = sizeof(float) * (8 * THIN_FPL + (size_t)p.in.a.C * 36);
+    if (set_lds(conv_fwd_thin_kernel, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd_thin: cannot reserve %zu B of LDS", lds);
+    const unsigned grid = (unsigned)p.B * ((p.Hout + 7) / 8) * ((p.Wout + 127) / 128);
+    hipLaunchKernelGGL(conv_fwd_thin_kernel, dim3(grid), dim3(THIN_T), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_fwd_thin launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
