@@ -66,7 +66,11 @@ int rvsr_modulated_deform_conv_forward(const float* input, const float* weight, 
  *   grad_offset, grad_mask: overwritten.   grad_weight, grad_bias: accumulated into (+=), the
  *   caller zeroes them (deform_conv.py:130-131, cpp:659-671).
  *   grad_input/grad_offset/grad_mask may be NULL together (skip), grad_weight may be NULL (skip).
- *   workspace: rvsr_modulated_deform_conv_backward_workspace_bytes() bytes, needed iff grad_weight. */
+ *   workspace: rvsr_modulated_deform_conv_backward_workspace_bytes() bytes, needed iff grad_weight.
+ *   The kernel for grad_input/grad_offset/grad_mask is chosen ON THE DEVICE from a sampled statistic
+ *   of `offset` (no host synchronisation): atomic-free private LDS windows for offsets within ~2 px,
+ *   a shared LDS tile with a 3 px / 5 px halo for larger ones; all candidates give the same result up
+ *   to the summation order of the scatter. */
 size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch, int channels, int height, int width,
                                                            int channels_out, int stride, int pad, int dil);
 int rvsr_modulated_deform_conv_backward(const float* input, const float* weight, const float* bias,
@@ -118,7 +122,11 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
  *   pixel_shuffle 1: out1 is (B,Co/4,2*Hout,2*Wout), written through PixelShuffle(2).
  *   stride 2 only with ksize 3 and in_mode 0.
  *   workspace: rvsr_conv2d_forward_workspace_bytes(C1, C2, Co1+Co2, ksize) bytes (holds the weights
- *   re-packed as bf16 hi/lo for the matrix cores; unused in exact-f32 mode). */
+ *   re-packed as bf16 hi/lo for the matrix cores; unused in exact-f32 mode).
+ *   Sizes: the fast kernels address one batch element of a tensor with 32-bit byte offsets (raw
+ *   buffers); an input whose C*Hs*Ws*4 bytes reach 2 GB, or a concat whose first input is not a
+ *   multiple of 16 channels, takes the scalar-staging / earlier-generation kernels (same results).
+ *   3x3 stride-1 layers with Co <= 4 (conv_last) run on the vector ALU in exact f32 in both modes. */
 size_t rvsr_conv2d_forward_workspace_bytes(int C1, int C2, int Co, int ksize);
 int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const float* xact, float xact_slope,
                         int in_mode, int Hs, int Ws, const float* weight, const float* bias,
