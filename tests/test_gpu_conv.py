@@ -102,6 +102,31 @@ def test_conv_block_forward_backward(case, gemm_mode):
     check('grad_bias', conv.bias.grad, br.grad, TOL)
 
 
+def _random_cases(n, seed):
+    """Seeded sweep over the shapes the buffer-addressed staging has to get right: channel counts that leave partial octets /
+    chunks, concat inputs on and off the 16 / 64-channel boundaries, widths on and off the vector path, ragged tiles."""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        k = rnd.choice([3, 3, 3, 1])
+        C1 = rnd.choice([3, 8, 9, 16, 24, 40, 64, 72])
+        C2 = rnd.choice([0, 0, 0, 16, 64]) if C1 % 8 == 0 else 0
+        Co = rnd.choice([1, 3, 4, 12, 32, 64, 80, 216]) if k == 3 else rnd.choice([16, 64])
+        ps = k == 3 and Co % 4 == 0 and Co >= 32 and rnd.random() < 0.25
+        act = rnd.choice(['none', 'relu', 'lrelu'])
+        use_res = (not ps) and rnd.random() < 0.3
+        H = rnd.choice([5, 8, 13, 16, 18, 33])
+        W = rnd.choice([8, 12, 20, 36, 68, 30])   # 30: off the vector path
+        out.append((C1, C2, Co, k, 1, act, use_res, ps, rnd.choice([1, 2, 3]), H, W))
+    return out
+
+
+@pytest.mark.parametrize('case', _random_cases(36, 20260928), ids=lambda c: '-'.join(str(v) for v in c))
+def test_conv_random_shapes(case, gemm_mode):
+    test_conv_block_forward_backward(case, gemm_mode)
+
+
 def test_conv_refuses_cpu_tensors():
     from realvsr_amd import functional as RF
     conv = nn.Conv2d(4, 4, 3, 1, 1)

@@ -82,6 +82,26 @@ def test_random_shapes_vs_oracle(shape, gemm_mode):
     _compare((x, off, m, w, b, stride, pad, dil, dg), gout, 2e-5 if gemm_mode == 'f32' else 1e-4)
 
 
+def _random_shapes(n, seed):
+    """Seeded sweep: channel / group counts on both sides of the 8-channel octet, ragged tiles, every offset regime of the
+    device-side backward selection (private windows, 3 px and 5 px halo, global fallback)."""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        dg = rnd.choice([1, 2, 4, 8])
+        C = dg * rnd.choice([4, 8, 8, 16])
+        Co = rnd.choice([8, 24, 64, 72, 128])
+        out.append((rnd.choice([1, 2]), C, Co, dg, rnd.choice([6, 9, 17, 24]), rnd.choice([8, 20, 33, 44]), 1, 1, 1,
+                    rnd.choice([0.3, 1.0, 2.5, 4.0, 9.0]), rnd.random() < 0.8))
+    return out
+
+
+@pytest.mark.parametrize('shape', _random_shapes(14, 928), ids=lambda s: '-'.join(str(v) for v in s))
+def test_random_sweep_vs_oracle(shape, gemm_mode):
+    test_random_shapes_vs_oracle(shape, gemm_mode)
+
+
 def test_identities(gemm_mode):
     TOL = 2e-5 if gemm_mode == 'f32' else 1e-4
     import torch.nn.functional as F
