@@ -170,10 +170,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
     float ain[ACT_IN ? NIT : 1][8];  // saved activation outputs (sign -> derivative), only for data gradients
     int nvalid[NIT];                 // number of real channels in the item's octet (0: position outside the image)
 
-    auto issue_loads = [&](int chunk) {
+    __amdgpu_buffer_rsrc_t xa_rs = buf_view_2g(va.p), xb_rs = buf_view_2g(va.p), act_rs = buf_view_2g(va.p);
+    auto tile_views = [&]() {   // buffer views of the current tile's batch element (plain view only)
+        if (va.mode != 0) return;
+        const size_t hw = (size_t)va.Hs * va.Ws;
+        xa_rs = buf_view_2g(va.p + (size_t)b * va.C * hw);
+        if (vb.C) xb_rs = buf_view_2g(vb.p + (size_t)b * vb.C * hw);
+        if (ACT_IN) act_rs = buf_view_2g(va.act + (size_t)b * va.C * hw);
+    };
+    // items i_lo .. i_hi-1 only (compile-time bounds after unrolling): the stride-2 instantiations stage NIT = 9 items = 72
+    // registers per thread and spilled 130-180 of them when all were in flight at once; they go in batches of NB
+    auto issue_loads = [&](int chunk, int i_lo = 0, int i_hi = 1 << 20) {
         const int c0 = chunk * 16 * CCG;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
+            if (i < i_lo || i >= i_hi) continue;
             const int it_raw = tid + i * NTHR;
             const bool live = it_raw < NOCT * NPOS;
             const int it = live ? it_raw : 0;
@@ -184,20 +195,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
             const bool inb = live && gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv && cb < Ctot;
             const int gyc = gy < 0 ? 0 : (gy >= va.Hv ? va.Hv - 1 : gy), gxc = gx < 0 ? 0 : (gx >= va.Wv ? va.Wv - 1 : gx);
             if (va.mode == 0) {  // (uniform branch)
-                const bool second = inb && cb >= C1;  // octets never straddle the two inputs (C1 % 8 == 0)
-                const float* bp = second ? vb.p : va.p;
-                const float* ap = va.act;             // act' fusion only exists for single-input data gradients
-                const int Cb = second ? vb.C : va.C;
-                const int cl = inb ? (second ? cb - C1 : cb) : 0;
-                const size_t hw = (size_t)va.Hs * va.Ws;
-                const size_t sp = (size_t)gyc * va.Ws + gxc;
-                nvalid[i] = inb ? (Cb - cl < 8 ? Cb - cl : 8) : 0;
+                // raw buffer loads (see conv_fwd5_kernel): the channel plane is a uniform byte offset, the lane offset is 32-bit,
+                // and everything that must read as zero (padding, channels beyond the tensor, threads without an item) gets
+                // an offset beyond the 2 GB view.  The scalar path paid a 64-bit multiply-add chain per loaded value.
+                const bool second = c0 >= C1;   // (uniform: rvsr_launch_conv_fwd2 requires C1 % chunk == 0 for a concat)
+                const int Cb = second ? vb.C : va.C, cl0 = second ? c0 - C1 : c0;
+                const unsigned hw4 = 4u * (unsigned)(va.Hs * va.Ws);
+                const bool pos_ok = live && gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv;
+                const unsigned vo = pos_ok ? 4u * (unsigned)(gy * va.Ws + gx) + (unsigned)(8 * oc) * hw4 : 0x80000000u;
+                const int lane_nch = Cb - cl0 - 8 * oc;
+                nvalid[i] = 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int cj = cl + j < Cb ? cl + j : Cb - 1;
-                    const size_t idx = ((size_t)b * Cb + cj) * hw + sp;
-                    vin[i][j] = bp[idx];
-                    if (ACT_IN) ain[i][j] = ap[idx];
+                    const unsigned vo_j = j < lane_nch ? vo : 0x80000000u;
+                    const unsigned so = (unsigned)(cl0 + j) * hw4;
+                    vin[i][j] = buf_load(second ? xb_rs : xa_rs, vo_j, so);
+                    if (ACT_IN) ain[i][j] = buf_load(act_rs, vo_j, so);
                 }
             } else {  // mode 2: pixel-unshuffle view, virtual channel c -> stored (c>>2, 2y+((c>>1)&1), 2x+(c&1))
                 const size_t hw = (size_t)va.Hs * va.Ws;
@@ -213,9 +226,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
             }
         }
     };
-    auto commit_inputs = [&]() {
+    auto commit_inputs = [&](int i_lo = 0, int i_hi = 1 << 20) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
+            if (i < i_lo || i >= i_hi) continue;
             const int it = tid + i * NTHR;
             float v[8];
 #pragma unroll
@@ -231,14 +245,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
             }
         }
     };
-    auto commit_to_lds = [&](int chunk) {
+    auto commit_to_lds = [&](int chunk, bool inputs_done = false) {
         // packed weights: straight 16-byte copy (L2-resident), in batches of <= 9 vectors per thread: all loads of
         // a batch are issued before its LDS writes.  When registers allow (forward variants) the first batch's
         // loads fly while the input tile is converted.
         const bf16x8* src = reinterpret_cast<const bf16x8*>(p.wpack) + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
         constexpr int WB = MT >= 4 ? 3 : 9;  // MT = 4 keeps 128 accumulator registers live: smaller batches
         constexpr bool OVERLAP = !ACT_IN && MT <= 2;
-        if (!OVERLAP) commit_inputs();
+        if (!OVERLAP && !inputs_done) commit_inputs();
 #pragma unroll
         for (int base = 0; base < NWV; base += WB) {
             bf16x8 wv[WB];
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
                 const int e = tid + (base + i) * NTHR;
                 wv[i] = src[(base + i < NWV && e < 2 * WVEC) ? e : 0];
             }
-            if (OVERLAP && base == 0) commit_inputs();
+            if (OVERLAP && base == 0 && !inputs_done) commit_inputs();
 #pragma unroll
             for (int i = 0; i < WB; ++i) {
                 const int e = tid + (base + i) * NTHR;
@@ -261,10 +275,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
     };
 
     // register prefetch only where the register file has room for it; the other variants stage synchronously
-    constexpr bool PF = !ACT_IN && MT <= 2;
+    constexpr bool PF = !ACT_IN && MT <= 2 && STRIDE == 1;   // (stride 2 stages 9 items = 72 registers per thread: prefetching them spilled 181)
     unsigned S = range0 + wq;
     if (S < range1) {
         decode(S);
+        tile_views();
         if (PF) issue_loads(0);
     }
     for (; S < range1; S += nwq) {
@@ -277,8 +292,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
         const int cx0 = x0, cy0 = y0, cmb = mb, cb_ = b;
         STAMP(0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            if (!PF) issue_loads(chunk);
-            commit_to_lds(chunk);
+            constexpr int NB = 3;
+            if (!PF && STRIDE == 2) {   // batched: NB items in flight at a time
+#pragma unroll
+                for (int i0 = 0; i0 < NIT; i0 += NB) {
+                    issue_loads(chunk, i0, i0 + NB);
+                    commit_inputs(i0, i0 + NB);
+                }
+                commit_to_lds(chunk, true);
+            } else {
+                if (!PF) issue_loads(chunk);
+                commit_to_lds(chunk);
+            }
             STAMP(1 + chunk * 5);
             __syncthreads();
             STAMP(2 + chunk * 5);
@@ -334,6 +359,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
         STAMP(30);
         if (S + nwq < range1) {  // the stores above are asynchronous: the next tile's loads go out right behind them
             decode(S + nwq);
+            tile_views();
             if (PF) issue_loads(0);
         }
         STAMP(31);
@@ -1148,6 +1174,12 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
     fwd2_geom(ksize, p.Co, Ctot, mt, ccg, nchunks, nmb);
     const size_t need = rvsr_conv_fwd2_workspace_bytes(ksize, p.Co, Ctot);
     if (!workspace || workspace_bytes < need) FAIL(RVSR_ERR_WORKSPACE, "conv2d: workspace %zu B < %zu B", workspace_bytes, need);
+    if ((ksize == 1 || stride == 2) && p.in.a.mode == 0) {
+        // conv_fwd2_kernel stages a plain view through raw buffer loads: 32-bit byte offsets inside one batch element (< 2 GB),
+        // and a concat boundary on a chunk boundary; anything else goes back to the exact-f32 kernels of conv_kernels.hip
+        const size_t span = sizeof(float) * (size_t)p.in.a.Hs * p.in.a.Ws * (size_t)(p.in.a.C > p.in.b.C ? p.in.a.C : p.in.b.C);
+        if (span >= ((size_t)1 << 31) || (p.in.b.C != 0 && p.in.a.C % (16 * ccg) != 0)) return RVSR_ERR_UNSUPPORTED;
+    }
     const int T = ksize * ksize;
     const size_t total = (size_t)nmb * nchunks * T * (2 * ccg) * (mt * 32);
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, p.Co,

@@ -342,8 +342,10 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
     hipStream_t st = (hipStream_t)stream;
     p.wpack = nullptr;
     if (rvsr_conv_fwd_thin_ok(p, ksize, stride)) return rvsr_launch_conv_fwd_thin(p, st);   // <= 4 output channels: vector ALU, exact f32
-    if (rvsr_g_gemm_mode == 0 && (in_mode != 1 || ksize == 3) && (x2 == nullptr || C1 % 8 == 0))
-        return rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
+    if (rvsr_g_gemm_mode == 0 && (in_mode != 1 || ksize == 3) && (x2 == nullptr || C1 % 8 == 0)) {
+        const int rc2 = rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
+        if (rc2 != RVSR_ERR_UNSUPPORTED) return rc2;   // (sizes beyond the buffer-addressed kernels: exact-f32 kernels below)
+    }
     const int mt = p.Co <= 32 ? 1 : (p.Co <= 64 ? 2 : 4);
 #define DISPATCH(KS, S, CC12, CC4)                                \
     do {                                                           \
