@@ -159,8 +159,10 @@ class TSA_Fusion(nn.Module):
             emb_ref = conv(aligned_fea[:, self.center] if center_fea is None else center_fea, self.tAtt_2)
             emb = conv(aligned_fea.view(-1, C, H, W), self.tAtt_1).view(B, N, -1, H, W)
             aligned_fea = RF.tsa_temporal(emb, emb_ref, aligned_fea)  # [B, N*C, H, W]
-        fea = conv(aligned_fea, self.fea_fusion, LRELU)
-        att = conv(aligned_fea, self.sAtt_1, LRELU)
+        # the modulated features feed two 1x1 convs: one gradient buffer for both (fea_fusion, created first, owns it)
+        sk = RF.GradSink() if (_USE_SINKS and torch.is_grad_enabled() and aligned_fea.requires_grad) else None
+        fea = conv(aligned_fea, self.fea_fusion, LRELU, sink=sk)
+        att = conv(aligned_fea, self.sAtt_1, LRELU, dep_sink=sk)
         att = conv(RF.maxavgpool(att), self.sAtt_2, LRELU)
         att_L = conv(att, self.sAtt_L1, LRELU)
         att_L = conv(RF.maxavgpool(att_L), self.sAtt_L2, LRELU)

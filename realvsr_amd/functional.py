@@ -96,9 +96,10 @@ class _Conv2dFused(Function):
     """act(conv2d(cat(x1, x2), w) + b) [+ residual] [-> PixelShuffle(2)]"""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle, sink=None):
+    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle, sink=None, dep_sink=None):
         _need_cuda(x1, x2, weight, bias, residual)
-        ctx.sink = sink   # GradSink of x1: this conv is its OWNER (see GradSink)
+        ctx.sink = sink           # GradSink of x1: this conv is its OWNER (see GradSink)
+        ctx.dep_sink = dep_sink   # GradSink of x1: this conv is a DEPOSITOR (single-input convs only)
         x1, x2, weight, bias, residual = _c(x1), _c(x2), _c(weight), _c(bias), _c(residual)
         B, C1, H, W = x1.shape
         C2 = 0 if x2 is None else x2.shape[1]
@@ -135,6 +136,9 @@ class _Conv2dFused(Function):
         if need_x1 or (x2 is not None and need_x2):
             # owner of a GradSink (single-input convs only): add this data gradient onto what the other consumers of x1 deposited
             dep = ctx.sink.close() if (ctx.sink is not None and x2 is None) else None
+            deposit = ctx.dep_sink is not None and x2 is None and not ctx.dep_sink.closed
+            if deposit and ctx.dep_sink.buf is not None:
+                dep = ctx.dep_sink.buf            # a later depositor: add in place
             gx1 = dep if dep is not None else torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
             in_mode = 2 if ps else (1 if stride == 2 else 0)
@@ -143,6 +147,9 @@ class _Conv2dFused(Function):
                                              gout.shape[3], _p(weight), None, _p(dep), _p(gx1), C1, _p(gx2), C2, B, k,
                                              1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
                        'conv2d_backward_data')
+            if deposit:   # the first depositor's output IS the sink's buffer (no zero fill); autograd gets no gradient from here
+                ctx.dep_sink.buf = gx1
+                gx1 = None
         if need_w or (has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(weight)
             gb = weight.new_empty(Co) if has_bias else None
@@ -153,7 +160,7 @@ class _Conv2dFused(Function):
                                                      Co, B, k, stride, Ho, Wo, 0, _p(ws), ws.numel(), _stream()),
                        'conv2d_backward_weight')
         gres = gout if has_res else None
-        return gx1, gx2, gw, gb, gres, None, None, None, None, None
+        return gx1, gx2, gw, gb, gres, None, None, None, None, None, None
 
 
 class _ResBlockFused(Function):
@@ -328,7 +335,7 @@ def res_block(x, conv1, conv2):
     return _ResBlockFused.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
 
 
-def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False, sink=None):
+def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False, sink=None, dep_sink=None):
     """Fused conv block driven by an ``nn.Conv2d`` parameter holder (weight, bias, stride).
 
     out = act(conv(cat(x, x2))) [+ residual]; with ``pixel_shuffle`` the activation commutes with
@@ -336,9 +343,9 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
     stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
     if residual is not None and act != ACT_NONE:
         # act'(.) is recovered from the saved activation output, so the residual is added outside
-        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle, sink)
+        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle, sink, dep_sink)
         return out + residual
-    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle, sink)
+    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle, sink, dep_sink)
 
 
 # ------------------------------------------------------------------------------------------ DCN
