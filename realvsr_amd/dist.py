@@ -67,7 +67,7 @@ class BucketedGradAllReduce:
                 p.register_post_accumulate_grad_hook(self._hook)
 
     def zero_grad(self):
-        self.flat.zero_()
+        self.buffers.zero_grad()
         self._pending = list(self._need)
         self._next = 0
         self._works = []
@@ -79,6 +79,7 @@ class BucketedGradAllReduce:
             self._next += 1
 
     def _hook(self, p):
+        self.buffers.rebind(p)   # (a gradient adopted from a plain torch module lives elsewhere: copy it into the bucket)
         self._pending[self._bucket_of[p]] -= 1
         self._issue_ready()
 
@@ -86,6 +87,7 @@ class BucketedGradAllReduce:
         """Wait for the in-flight buckets and turn the sums into means. Call before optimizer.step()."""
         if self.world == 1:
             return
+        self.buffers.rebind()
         self.buffers.check_bound()
         for b in range(self._next, len(self.buckets)):   # buckets holding parameters that got no gradient this step
             self._pending[b] = 0

@@ -8,6 +8,8 @@ codes/models/archs/dcn/deform_conv.py:109-110,124-125).
 import ctypes
 import functools
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -91,6 +93,27 @@ class GradSink:
         return buf
 
 
+_ADOPT_FLAT_GRADS = os.environ.get('RVSR_FLAT_GRAD_ADOPT', '1') != '0'   # developer A/B switch
+
+
+def _pgrad(p, zero=False):
+    """Output buffer for the gradient of parameter `p` inside a fused backward.
+
+    When the parameter lives in optim.FlatBuffers and has no gradient yet this step (``p.grad is None`` after
+    FlatBuffers.zero_grad), the buffer is the parameter's own view of the flat gradient buffer: the kernel writes the gradient
+    where the optimizer and the bucketed all-reduce read it, autograd's AccumulateGrad adopts the returned view as ``p.grad``
+    (no ``grad += new`` kernel, no temporary).  Otherwise (second use of a shared parameter, gradient accumulation over several
+    backward passes, parameters outside FlatBuffers) an ordinary temporary, summed by autograd as usual."""
+    home = getattr(p, '_rvsr_grad_home', None) if p is not None else None
+    if home is not None and p.grad is None and p.dtype == torch.float32 and _ADOPT_FLAT_GRADS:
+        buf, off = home
+        v = buf[off:off + p.numel()].view(p.shape)
+        if zero:
+            v.zero_()   # (accumulating kernels: do not rely on the caller having used FlatBuffers.zero_grad)
+        return v
+    return torch.zeros_like(p) if zero else torch.empty_like(p)
+
+
 # ------------------------------------------------------------------------------------------ conv
 class _Conv2dFused(Function):
     """act(conv2d(cat(x1, x2), w) + b) [+ residual] [-> PixelShuffle(2)]"""
@@ -120,6 +143,7 @@ class _Conv2dFused(Function):
         ctx.cfg = (stride, act, slope, bool(pixel_shuffle), C1, C2, H, W, Ho, Wo, k, bias is not None,
                    residual is not None)
         ctx.save_for_backward(x1, x2, weight, out if act != ACT_NONE else None)
+        ctx.bias_p = bias   # only to find its gradient buffer (_pgrad)
         return out
 
     @staticmethod
@@ -151,8 +175,8 @@ class _Conv2dFused(Function):
                 ctx.dep_sink.buf = gx1
                 gx1 = None
         if need_w or (has_bias and ctx.needs_input_grad[3]):
-            gw = torch.empty_like(weight)
-            gb = weight.new_empty(Co) if has_bias else None
+            gw = _pgrad(weight)
+            gb = _pgrad(ctx.bias_p) if has_bias else None
             nbytes = L.rvsr_conv2d_wgrad_workspace_bytes(C1, C2, Co, B, k, stride, Ho, Wo)
             ws = _workspace(nbytes, x1.device)
             _lib.check(L.rvsr_conv2d_backward_weight(_p(x1), C1, _p(x2), C2, H, W, _p(gout), _p(act_out), gslope,
@@ -188,6 +212,7 @@ class _ResBlockFused(Function):
                    'res_block conv2')
         ctx.save_for_backward(x, h, w1, w2)
         ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.bias_p = (b1, b2)   # only to find their gradient buffers (_pgrad)
         return out
 
     @staticmethod
@@ -201,8 +226,8 @@ class _ResBlockFused(Function):
         gx = gw1 = gb1 = gw2 = gb2 = None
         nb = L.rvsr_conv2d_wgrad_workspace_bytes(C, 0, C, B, 3, 1, H, W)
         if need_w2 or need_b2:
-            gw2 = torch.empty_like(w2)
-            gb2 = w2.new_empty(C) if ctx.has_bias[1] else None
+            gw2 = _pgrad(w2)
+            gb2 = _pgrad(ctx.bias_p[1]) if ctx.has_bias[1] else None
             ws = _workspace(nb, x.device)
             _lib.check(L.rvsr_conv2d_backward_weight(_p(h), C, None, 0, H, W, _p(gout), None, 0.0, 0, H, W, _p(gw2),
                                                      _p(gb2), C, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()),
@@ -215,8 +240,8 @@ class _ResBlockFused(Function):
                                              None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(),
                                              _stream()), 'res_block dgrad2')
             if need_w1 or need_b1:
-                gw1 = torch.empty_like(w1)
-                gb1 = w1.new_empty(C) if ctx.has_bias[0] else None
+                gw1 = _pgrad(w1)
+                gb1 = _pgrad(ctx.bias_p[0]) if ctx.has_bias[0] else None
                 ws = _workspace(nb, x.device)
                 _lib.check(L.rvsr_conv2d_backward_weight(_p(x), C, None, 0, H, W, _p(gh), _p(h), 0.0, 0, H, W,
                                                          _p(gw1), _p(gb1), C, B, 3, 1, H, W, 0, _p(ws), ws.numel(),
@@ -433,6 +458,7 @@ class _DcnPackFused(Function):
                    'dcn_pack_forward')
         ctx.cfg = (stride, padding, dilation, dg, act, slope, bias is not None)
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
+        ctx.bias_p = bias   # only to find its gradient buffer (_pgrad)
         return out
 
     @staticmethod
@@ -446,8 +472,8 @@ class _DcnPackFused(Function):
         dep = ctx.sink.get(x) if ctx.sink is not None else None
         gx = dep if dep is not None else torch.zeros_like(x)
         gom = torch.empty_like(om)
-        gw = torch.zeros_like(weight)
-        gb = weight.new_zeros(Co) if has_bias else None
+        gw = _pgrad(weight, zero=True)   # (the DCN backward accumulates into grad_weight / grad_bias)
+        gb = _pgrad(ctx.bias_p, zero=True) if has_bias else None
         L = _lib.lib()
         nbytes = L.rvsr_modulated_deform_conv_backward_workspace_bytes(B, C, H, W, Co, stride, padding, dilation)
         ws = _workspace(nbytes, x.device)
@@ -583,6 +609,7 @@ class _TSATemporalBlock(Function):
                    'tsa_temporal_forward')
         ctx.center = center
         ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.bias_p = (b1, b2)   # only to find their gradient buffers (_pgrad)
         ctx.save_for_backward(aligned, emb, emb_ref, prob, w1, w2)
         return mod
 
@@ -600,14 +627,14 @@ class _TSATemporalBlock(Function):
         gw1 = gb1 = gw2 = gb2 = None
         cen = aligned[center]
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            gw1 = torch.empty_like(w1)
-            gb1 = w1.new_empty(C) if ctx.has_bias[0] else None
+            gw1 = _pgrad(w1)
+            gb1 = _pgrad(ctx.bias_p[0]) if ctx.has_bias[0] else None
             ws = _workspace(L.rvsr_conv2d_wgrad_workspace_bytes(C, 0, C, N * B, 3, 1, H, W), aligned.device)
             _lib.check(L.rvsr_conv2d_backward_weight(_p(aligned), C, None, 0, H, W, _p(gemb), None, 0.0, 0, H, W, _p(gw1), _p(gb1),
                                                      C, N * B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'tsa wgrad tAtt_1')
         if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
-            gw2 = torch.empty_like(w2)
-            gb2 = w2.new_empty(C) if ctx.has_bias[1] else None
+            gw2 = _pgrad(w2)
+            gb2 = _pgrad(ctx.bias_p[1]) if ctx.has_bias[1] else None
             ws = _workspace(L.rvsr_conv2d_wgrad_workspace_bytes(C, 0, C, B, 3, 1, H, W), aligned.device)
             _lib.check(L.rvsr_conv2d_backward_weight(_p(cen), C, None, 0, H, W, _p(gemb_ref), None, 0.0, 0, H, W, _p(gw2), _p(gb2),
                                                      C, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'tsa wgrad tAtt_2')

@@ -55,22 +55,45 @@ class FlatBuffers:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + n].view(p.shape)
+                # where the fused operators of realvsr_amd.functional write this parameter's gradient (see zero_grad)
+                p._rvsr_grad_home = (self.grad, o)
 
     def grad_view(self, p):
         o = self.offset[p]
         return self.grad[o:o + p.numel()].view(p.shape)
 
+    def zero_grad(self):
+        """One memset, and every ``p.grad`` becomes None until backward fills it.  With ``p.grad is None`` autograd's
+        AccumulateGrad ADOPTS the incoming gradient tensor instead of adding it to an existing one, and the fused operators
+        produce that tensor as the parameter's own view of the flat buffer (functional._pgrad): the gradient kernels write
+        straight into the flat buffer and the 144 tiny ``grad += new`` kernels (and 144 temporaries) of a step disappear.
+        Gradients that arrive from elsewhere (plain torch modules) are copied home by ``rebind``."""
+        self.grad.zero_()
+        for p in self.order:
+            p.grad = None
+
+    def rebind(self, p=None):
+        """Make ``p.grad`` (all parameters if None) the flat view again: zeros if no gradient arrived, a copy if autograd
+        adopted a tensor that lives elsewhere."""
+        for q in (self.order if p is None else (p,)):
+            o = self.offset[q]
+            if q.grad is None:
+                q.grad = self.grad[o:o + q.numel()].view(q.shape)
+            elif q.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                view = self.grad[o:o + q.numel()].view(q.shape)
+                view.copy_(q.grad)
+                q.grad = view
+
     def check_bound(self):
-        """Raise if something re-bound a parameter or its gradient away from the flat buffers (net.to(), zero_grad(
-        set_to_none=True), p.grad = None, ...): the flat update would then silently work on stale memory."""
+        """Raise if something re-bound a parameter away from the flat buffers (net.to(), load with assign) or left a gradient
+        outside them: the flat update would then silently work on stale memory.  (``p.grad is None`` = no gradient yet.)"""
         base_p, base_g = self.param.data_ptr(), self.grad.data_ptr()
         for p in self.order:
             o = 4 * self.offset[p]
             if p.data_ptr() != base_p + o:
                 raise RuntimeError('a parameter was moved out of the flat buffer (module.to()/load with assign?)')
-            if p.grad is None or p.grad.data_ptr() != base_g + o:
-                raise RuntimeError('a gradient was detached from the flat buffer (zero_grad(set_to_none=True) or '
-                                   'p.grad = None); use the optimizer\'s / reducer\'s zero_grad()')
+            if p.grad is not None and p.grad.data_ptr() != base_g + o:
+                raise RuntimeError('a gradient lives outside the flat buffer; FlatBuffers.rebind() copies it home')
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -94,7 +117,7 @@ class FlatAdam(torch.optim.Optimizer):
                                  'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape)}
 
     def zero_grad(self, set_to_none=False):
-        self.buffers.grad.zero_()
+        self.buffers.zero_grad()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -102,6 +125,7 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.buffers.rebind()
         self.buffers.check_bound()
         for gi, (group, (s, e)) in enumerate(zip(self.param_groups, self.buffers.group_range)):
             if e == s:

@@ -162,7 +162,7 @@ def test_flat_adam_matches_torch_adam(wd):
         opt_t.zero_grad()
         for po, pt in zip(ours, theirs):
             gr = torch.randn(po.shape, device=dev()) * (10.0 ** -step)
-            po.grad.copy_(gr)
+            po.grad = gr.clone()   # (after zero_grad() p.grad is None; step() copies a foreign gradient into the flat buffer)
             pt.grad = gr.clone()
         if step == 3:
             opt_o.param_groups[1]['lr'] = 5e-4    # schedulers edit param_groups in place (base_model.py:36-60)
@@ -177,9 +177,18 @@ def test_flat_adam_matches_torch_adam(wd):
     opt_o.load_state_dict(sd)
     assert opt_o.state[ours[0]]['exp_avg'].data_ptr() == opt_o.exp_avg.data_ptr() + 4 * opt_o.buffers.offset[ours[0]]
     assert int(opt_o.state[ours[0]]['step']) == 5
+    # p.grad = None means "no gradient this step" (FlatBuffers.zero_grad leaves it so): step() rebinds it to its zeroed flat view;
+    # a gradient that lives elsewhere is copied home; a PARAMETER moved out of the flat buffer is an error
+    opt_o.zero_grad()
     ours[0].grad = None
+    ours[1].grad = torch.ones_like(ours[1])
+    opt_o.step()
+    b = opt_o.buffers
+    assert ours[0].grad.data_ptr() == b.grad.data_ptr() + 4 * b.offset[ours[0]] and float(ours[0].grad.abs().sum()) == 0
+    assert ours[1].grad.data_ptr() == b.grad.data_ptr() + 4 * b.offset[ours[1]] and float(ours[1].grad.min()) == 1.0
+    ours[0].data = ours[0].data.clone()
     with pytest.raises(RuntimeError):
-        opt_o.step()                               # detached gradient is detected, not silently ignored
+        opt_o.step()
 
 
 # ------------------------------------------------------------------------------------------ the training step

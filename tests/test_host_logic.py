@@ -109,6 +109,26 @@ def test_flat_buffers_layout_and_guards():
     net(torch.randn(2, 3, 6, 6)).sum().backward()
     assert float(fb.grad.abs().sum()) > 0                      # autograd accumulated into the views
     fb.check_bound()
-    net.zero_grad(set_to_none=True)
+    # zero_grad: one memset, p.grad = None until backward delivers (autograd then ADOPTS the incoming tensor; the fused operators
+    # deliver the flat view itself, a plain torch module delivers a temporary that rebind() copies home)
+    fb.zero_grad()
+    assert all(p.grad is None for p in net.parameters()) and float(fb.grad.abs().sum()) == 0
+    fb.check_bound()
+    net(torch.randn(2, 3, 6, 6)).sum().backward()
     with pytest.raises(RuntimeError):
-        fb.check_bound()
+        fb.check_bound()                                       # adopted temporaries live outside the flat buffer ...
+    want = [p.grad.clone() for p in net.parameters()]
+    fb.rebind()
+    fb.check_bound()                                           # ... until rebind() copies them home
+    for p, w in zip(net.parameters(), want):
+        assert p.grad.data_ptr() == fb.grad.data_ptr() + 4 * fb.offset[p] and torch.equal(p.grad, w)
+    net.zero_grad(set_to_none=True)
+    fb.rebind()
+    fb.check_bound()
+    # the hook the fused operators use: a parameter without a gradient gets its flat view as the output buffer
+    from realvsr_amd.functional import _pgrad
+    p0 = next(net.parameters())
+    p0.grad = None
+    assert _pgrad(p0).data_ptr() == fb.grad.data_ptr() + 4 * fb.offset[p0]
+    p0.grad = torch.zeros_like(p0)
+    assert _pgrad(p0).data_ptr() != fb.grad.data_ptr() + 4 * fb.offset[p0]
