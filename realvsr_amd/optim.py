@@ -5,8 +5,10 @@
 MI355X-first layout: every parameter of the network is a view into one contiguous f32 buffer, every gradient a view
 into a second one laid out identically (the buffer ``realvsr_amd.dist.BucketedGradAllReduce`` all-reduces in
 buckets), and the two Adam moments are two more.  The update is then a single streaming pass over 4 x 13 MB
-(EDVR-M) instead of torch's multi-tensor chain over 144 tensors; ``zero_grad`` is one memset and can never detach a
-gradient from the reduced buffer (torch's ``set_to_none`` default would).
+(EDVR-M) instead of torch's multi-tensor chain over 144 tensors; ``zero_grad`` is one memset that also sets every
+``p.grad`` to None, so that autograd ADOPTS the gradient tensors of the next backward -- which the fused operators hand over
+as the parameters' own views of the flat gradient buffer (no per-parameter ``grad += new`` kernels); gradients that arrive
+from elsewhere are copied home (``FlatBuffers.rebind``) before the buffer is reduced or consumed.
 
 Arithmetic = torch's single-tensor Adam (amsgrad=False), op for op (rvsr_adam_step in csrc/train_kernels.hip);
 ``param_groups`` / ``state`` keep torch's schema, so LR schedulers that edit ``param_groups[i]['lr']``
