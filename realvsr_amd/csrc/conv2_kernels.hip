@@ -763,7 +763,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 const int gy = t.y0 - PAD + r, gx = t.x0 - 4 + 4 * g;
                 it_oc[i] = oc;
                 it_pos_ok[i] = live && gy >= 0 && gy < va.Hv && gx >= 0 && gx < va.Wv;
-                it_sp[i] = it_pos_ok[i] ? (VEC == 2 ? 8 * (gy * va.Ws + gx) : 4 * (gy * va.Ws + gx)) : (int)0x80000000;   // (mode 2: stored row 2 gy, column 2 gx)
+                if (VEC == 3)   // zero-insert view: only even virtual rows hold data, at stored (gy / 2, gx / 2) and (gy / 2, gx / 2 + 1)
+                    it_sp[i] = it_pos_ok[i] && !(gy & 1) && (gy >> 1) < va.Hs ? 4 * ((gy >> 1) * va.Ws + (gx >> 1)) : (int)0x80000000;
+                else
+                    it_sp[i] = it_pos_ok[i] ? (VEC == 2 ? 8 * (gy * va.Ws + gx) : 4 * (gy * va.Ws + gx)) : (int)0x80000000;   // (mode 2: stored row 2 gy, column 2 gx)
                 it_dst[i] = live ? (oc * IH + r) * IW + 4 * g - 3 : -100;  // LDS slot of the group's first pixel
             } else {
                 const int it_raw = tid + i * NTHR;
@@ -840,6 +843,24 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 return;
             }
             const unsigned vo = (unsigned)it_sp[0] + (unsigned)(8 * it_oc[0]) * hw4;
+            if (VEC == 3) {
+                // zero-insert view (the data gradient of a stride-2 conv): of an item's 4 virtual pixels only 0 and 2 hold data --
+                // one 8-byte load per channel; pixels 1 and 3, and every odd virtual row, are zeros
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (xsel >= 0 && (j >> 2) != xsel) continue;
+                    const unsigned so = (unsigned)(cl0 + j) * hw4;
+                    const unsigned vo_j = j < lane_nch ? vo : 0x80000000u;
+                    const f32x2v q = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(xa_rs, (int)vo_j, (int)so, 0));
+                    vin[0][j][0] = q.x; vin[0][j][NV > 2 ? 2 : 0] = q.y; vin[0][j][NV > 1 ? 1 : 0] = 0.f; vin[0][j][NV > 3 ? 3 : 0] = 0.f;
+                    if (ACT_IN) {
+                        const f32x2v a2 = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(act_rs, (int)vo_j, (int)so, 0));
+                        ain[0][j][0] = a2.x; ain[0][j][NV > 2 ? 2 : 0] = a2.y; ain[0][j][NV > 1 ? 1 : 0] = 1.f; ain[0][j][NV > 3 ? 3 : 0] = 1.f;
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (xsel >= 0 && (j >> 2) != xsel) continue;
@@ -1135,8 +1156,13 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
     else if (va.mode == 2 && vb.C == 0 && va.C % 16 == 0 && va.Wv % 4 == 0 && va.Ws == 2 * va.Wv && va.Hs == 2 * va.Hv && al16 &&
              plane * (size_t)(va.C >> 2) < ((size_t)1 << 31))
         vec = 2;
-    auto k = va.act != nullptr ? (vec == 2 ? conv_fwd5_kernel<MT, true, 2> : vec ? conv_fwd5_kernel<MT, true, 1> : conv_fwd5_kernel<MT, true, 0>)
-                               : (vec == 2 ? conv_fwd5_kernel<MT, false, 2> : vec ? conv_fwd5_kernel<MT, false, 1> : conv_fwd5_kernel<MT, false, 0>);
+    else if (va.mode == 1 && vb.C == 0 && va.Wv % 4 == 0 && va.Wv == 2 * va.Ws && va.Hv <= 2 * va.Hs && va.Ws % 2 == 0 && al16 &&
+             plane * (size_t)va.C < ((size_t)1 << 31))
+        vec = 3;
+    auto k = va.act != nullptr ? (vec == 3 ? conv_fwd5_kernel<MT, true, 3> : vec == 2 ? conv_fwd5_kernel<MT, true, 2>
+                                  : vec ? conv_fwd5_kernel<MT, true, 1> : conv_fwd5_kernel<MT, true, 0>)
+                               : (vec == 3 ? conv_fwd5_kernel<MT, false, 3> : vec == 2 ? conv_fwd5_kernel<MT, false, 2>
+                                  : vec ? conv_fwd5_kernel<MT, false, 1> : conv_fwd5_kernel<MT, false, 0>);
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd5: cannot reserve %zu B of LDS", lds);
     const int nty = (p.Hout + 15) / 16;
     const long items = (long)p.ntx * nty * ((p.Co + MT * 32 - 1) / (MT * 32)) * p.B;
