@@ -7,7 +7,7 @@ P3="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_ACTIVE_IN
 i=0
 for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); d=$O/tmp
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $d -- python tools/conv_micro.py > /dev/null 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $d -- python tools/conv_micro.py --bwd > /dev/null 2>&1
   f=$(find $d -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py "$f" conv > $O/p$i.txt && cat $O/p$i.txt | grep -v pack
   rm -rf $d
