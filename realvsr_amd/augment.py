@@ -37,7 +37,9 @@ def _draw_blend(plan, prob, alpha):
     plan.v = float(np.random.uniform(alpha, 1))
 
 
-def _draw_cutblur(plan, size, prob, alpha):
+def _draw_cutblur(plan, size, prob, alpha, size1=None):
+    if size1 is not None and tuple(size1) != tuple(size):   # checked BEFORE any draw, as the reference does (:55-56)
+        raise ValueError('im1 and im2 have to be the same resolution.')
     if alpha <= 0 or np.random.rand(1) >= prob:
         return
     cut_ratio = np.random.randn() * 0.01 + alpha
@@ -48,9 +50,12 @@ def _draw_cutblur(plan, size, prob, alpha):
     inside = np.random.random() > 0.5
     plan.fired = True
     plan.box_mode = 1 if inside else 2
-    # python slice semantics of [cy:cy+ch, cx:cx+cw] on the last two dimensions (clamped like a slice)
+    # python slice semantics of [cy:cy+ch, cx:cx+cw] on the last two dimensions: clamped, and a NEGATIVE stop (alpha near 0
+    # makes ch / cw negative) counts from the end, exactly as the reference's slice assignment does
     H, W = size[-2], size[-1]
-    plan.box = (min(cy, H), min(cy + ch, H), min(cx, W), min(cx + cw, W))
+    ys, ye, _ = slice(cy, cy + ch).indices(H)
+    xs, xe, _ = slice(cx, cx + cw).indices(W)
+    plan.box = (ys, max(ye, ys), xs, max(xe, xs))
 
 
 def _draw_rgb(plan, prob):
@@ -60,8 +65,9 @@ def _draw_rgb(plan, prob):
     plan.perm = tuple(int(i) for i in np.random.permutation(3))
 
 
-def draw_plan(size, augs, probs, alphas, mix_p=None):
-    """Host-side draw for clips of shape ``size``; numpy RNG call order = apply_augment + the chosen augmentation."""
+def draw_plan(size, augs, probs, alphas, mix_p=None, size1=None):
+    """Host-side draw for clips of shape ``size`` (im2; ``size1`` = im1's shape when known); numpy RNG call order =
+    apply_augment + the chosen augmentation."""
     idx = np.random.choice(len(augs), p=mix_p)
     aug, prob, alpha = augs[idx], float(probs[idx]), float(alphas[idx])
     plan = AugPlan()
@@ -70,7 +76,7 @@ def draw_plan(size, augs, probs, alphas, mix_p=None):
     elif aug == 'blend':
         _draw_blend(plan, prob, alpha)
     elif aug == 'cutblur':
-        _draw_cutblur(plan, size, prob, alpha)
+        _draw_cutblur(plan, size, prob, alpha, size1)
     elif aug == 'rgb':
         _draw_rgb(plan, prob)
     else:
@@ -96,7 +102,7 @@ def apply_plan(im1, im2, plan):
 
 
 def apply_augment(im1, im2, augs, probs, alphas, mix_p=None):
-    return apply_plan(im1, im2, draw_plan(tuple(im2.shape), augs, probs, alphas, mix_p))
+    return apply_plan(im1, im2, draw_plan(tuple(im2.shape), augs, probs, alphas, mix_p, size1=tuple(im1.shape)))
 
 
 def blend(im1, im2, prob=1.0, alpha=0.6):

@@ -99,18 +99,23 @@ _ADOPT_FLAT_GRADS = os.environ.get('RVSR_FLAT_GRAD_ADOPT', '1') != '0'   # devel
 def _pgrad(p, zero=False):
     """Output buffer for the gradient of parameter `p` inside a fused backward.
 
-    When the parameter lives in optim.FlatBuffers and has no gradient yet this step (``p.grad is None`` after
-    FlatBuffers.zero_grad), the buffer is the parameter's own view of the flat gradient buffer: the kernel writes the gradient
-    where the optimizer and the bucketed all-reduce read it, autograd's AccumulateGrad adopts the returned view as ``p.grad``
-    (no ``grad += new`` kernel, no temporary).  Otherwise (second use of a shared parameter, gradient accumulation over several
-    backward passes, parameters outside FlatBuffers) an ordinary temporary, summed by autograd as usual."""
+    When the parameter lives in optim.FlatBuffers, has no gradient yet this step (``p.grad is None`` after
+    FlatBuffers.zero_grad) and its home has not been handed out since that zero_grad, the buffer is the parameter's own view of
+    the flat gradient buffer: the kernel writes the gradient where the optimizer and the bucketed all-reduce read it, and
+    autograd's AccumulateGrad adopts the returned view as ``p.grad`` (no ``grad += new`` kernel, no temporary).  The home is
+    handed out ONCE per zero_grad (FlatBuffers.claimed): a parameter used by several fused operators in one backward (a module
+    applied twice, shared weights) gets an ordinary temporary for every later use -- AccumulateGrad has not run between the uses,
+    so ``p.grad`` is still None and a second hand-out would alias the first gradient.  Gradient accumulation over several
+    backward passes and parameters outside FlatBuffers also take the temporary; autograd sums as usual."""
     home = getattr(p, '_rvsr_grad_home', None) if p is not None else None
     if home is not None and p.grad is None and p.dtype == torch.float32 and _ADOPT_FLAT_GRADS:
-        buf, off = home
-        v = buf[off:off + p.numel()].view(p.shape)
-        if zero:
-            v.zero_()   # (accumulating kernels: do not rely on the caller having used FlatBuffers.zero_grad)
-        return v
+        buf, off, claimed = home
+        if id(p) not in claimed:
+            claimed.add(id(p))
+            v = buf[off:off + p.numel()].view(p.shape)
+            if zero:
+                v.zero_()   # (accumulating kernels: do not rely on the caller having used FlatBuffers.zero_grad)
+            return v
     return torch.zeros_like(p) if zero else torch.empty_like(p)
 
 
@@ -120,6 +125,9 @@ class _Conv2dFused(Function):
 
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle, sink=None, dep_sink=None):
+        if x2 is not None and (sink is not None or dep_sink is not None):
+            # an owner that never closes drops what the depositors wrote: sinks are for single-input convs only
+            raise RuntimeError('conv2d: a GradSink cannot be combined with a second (concatenated) input')
         _need_cuda(x1, x2, weight, bias, residual)
         ctx.sink = sink           # GradSink of x1: this conv is its OWNER (see GradSink)
         ctx.dep_sink = dep_sink   # GradSink of x1: this conv is a DEPOSITOR (single-input convs only)
@@ -157,6 +165,9 @@ class _Conv2dFused(Function):
         gslope = 0.0 if act == ACT_RELU else slope
         need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gx1 = gx2 = gw = gb = None
+        if ctx.sink is not None and not need_x1:
+            # the owner always closes: what the depositors wrote is x1's gradient even if autograd wants none from this conv
+            ctx.sink.close()
         if need_x1 or (x2 is not None and need_x2):
             # owner of a GradSink (single-input convs only): add this data gradient onto what the other consumers of x1 deposited
             dep = ctx.sink.close() if (ctx.sink is not None and x2 is None) else None

@@ -12,7 +12,12 @@ from elsewhere are copied home (``FlatBuffers.rebind``) before the buffer is red
 
 Arithmetic = torch's single-tensor Adam (amsgrad=False), op for op (rvsr_adam_step in csrc/train_kernels.hip);
 ``param_groups`` / ``state`` keep torch's schema, so LR schedulers that edit ``param_groups[i]['lr']``
-(base_model.py:36-60) and ``state_dict()`` work unchanged.
+(base_model.py:36-60) and ``state_dict()`` work unchanged.  Two behaviours of torch.optim.Adam that a dense flat update
+would otherwise lose are kept: a parameter whose ``grad`` is None at step time is skipped entirely (no moment decay, no
+weight decay, no drift: its three ranges are restored after the launch; the step count that sets the bias corrections is
+kept per GROUP, so such a parameter follows its group's schedule afterwards where torch's per-parameter count would lag), and emptying ``optimizer.state`` -- what the
+reference's MultiStepLR_Restart(clear_state=True) does at a restart (codes/models/lr_scheduler.py) -- resets the flat
+moments and step counters (``reset_state``).
 """
 import math
 
@@ -50,6 +55,9 @@ class FlatBuffers:
         self.numel = off
         self.param = torch.zeros(off, dtype=torch.float32, device=ref.device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=ref.device)
+        # ids of the parameters whose flat gradient view a fused backward has been given since the last zero_grad
+        # (functional._pgrad hands a home out once; see there)
+        self.claimed = set()
         with torch.no_grad():
             for p in self.order:
                 o, n = self.offset[p], p.numel()
@@ -58,7 +66,7 @@ class FlatBuffers:
                 p.data = view
                 p.grad = self.grad[o:o + n].view(p.shape)
                 # where the fused operators of realvsr_amd.functional write this parameter's gradient (see zero_grad)
-                p._rvsr_grad_home = (self.grad, o)
+                p._rvsr_grad_home = (self.grad, o, self.claimed)
 
     def grad_view(self, p):
         o = self.offset[p]
@@ -71,16 +79,20 @@ class FlatBuffers:
         straight into the flat buffer and the 144 tiny ``grad += new`` kernels (and 144 temporaries) of a step disappear.
         Gradients that arrive from elsewhere (plain torch modules) are copied home by ``rebind``."""
         self.grad.zero_()
+        self.claimed.clear()
         for p in self.order:
             p.grad = None
 
     def rebind(self, p=None):
         """Make ``p.grad`` (all parameters if None) the flat view again: zeros if no gradient arrived, a copy if autograd
-        adopted a tensor that lives elsewhere."""
+        adopted a tensor that lives elsewhere.  A home that a fused backward wrote but autograd never adopted
+        (``torch.autograd.grad``: the result went to the caller, not to ``p.grad``) is not a gradient of this step: zeroed."""
         for q in (self.order if p is None else (p,)):
             o = self.offset[q]
             if q.grad is None:
                 q.grad = self.grad[o:o + q.numel()].view(q.shape)
+                if id(q) in self.claimed:
+                    q.grad.zero_()
             elif q.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 view = self.grad[o:o + q.numel()].view(q.shape)
                 view.copy_(q.grad)
@@ -110,6 +122,12 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.buffers.param)
         self._steps = [0] * len(self.param_groups)
         self._step_t = [torch.tensor(0.0) for _ in self.param_groups]  # one host tensor per group, shared by its params
+        self._bind_state()
+
+    def zero_grad(self, set_to_none=False):
+        self.buffers.zero_grad()
+
+    def _bind_state(self):
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
                 if not p.requires_grad:
@@ -118,8 +136,14 @@ class FlatAdam(torch.optim.Optimizer):
                 self.state[p] = {'step': self._step_t[gi], 'exp_avg': self.exp_avg[o:o + n].view(p.shape),
                                  'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape)}
 
-    def zero_grad(self, set_to_none=False):
-        self.buffers.zero_grad()
+    def reset_state(self):
+        """Forget the moments and step counts (torch: ``optimizer.state = defaultdict(dict)``)."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self._steps = [0] * len(self.param_groups)
+        for t in self._step_t:
+            t.fill_(0.0)
+        self._bind_state()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -127,6 +151,12 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if len(self.state) == 0:          # a scheduler cleared the state (restart): start the moments over
+            self.reset_state()
+        # torch skips parameters without a gradient; the flat launch touches every element, so keep what must not move
+        skipped = [(o, o + p.numel()) for p, o in self.buffers.offset.items() if p.grad is None]
+        saved = [(s, e, self.buffers.param[s:e].clone(), self.exp_avg[s:e].clone(), self.exp_avg_sq[s:e].clone())
+                 for s, e in skipped]
         self.buffers.rebind()
         self.buffers.check_bound()
         for gi, (group, (s, e)) in enumerate(zip(self.param_groups, self.buffers.group_range)):
@@ -141,6 +171,10 @@ class FlatAdam(torch.optim.Optimizer):
             RF.adam_step_(self.buffers.param[s:e], self.buffers.grad[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
                           step_size, beta1, beta2, group['eps'], group['weight_decay'], math.sqrt(bias_correction2))
             self._step_t[gi].fill_(float(t))
+        for s, e, pv, m1, m2 in saved:
+            self.buffers.param[s:e].copy_(pv)
+            self.exp_avg[s:e].copy_(m1)
+            self.exp_avg_sq[s:e].copy_(m2)
         return loss
 
     def load_state_dict(self, state_dict):

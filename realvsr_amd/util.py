@@ -3,6 +3,8 @@
 ``kernel`` arguments are accepted for signature compatibility; the binomial weights are
 compile-time constants of the HIP kernels (the reference rebuilds and uploads the tensor on
 every loss call).  Passing a kernel other than gauss_kernel() raises."""
+import weakref
+
 import torch
 
 from . import functional as RF
@@ -10,32 +12,37 @@ from . import functional as RF
 
 def gauss_kernel(size=5, device=torch.device('cpu'), channels=3):
     k1 = torch.tensor([1., 4., 6., 4., 1.])
-    kernel = (torch.outer(k1, k1) / 256.).repeat(channels, 1, 1, 1)
-    return kernel.to(device)
+    kernel = (torch.outer(k1, k1) / 256.).repeat(channels, 1, 1, 1).to(device)
+    kernel._rvsr_gain = 1.0   # built here: _kernel_gain need not read it back (valid while _version stays 0)
+    return kernel
 
 
-_checked_kernels = {}
+_checked_kernels = {}   # id(tensor) -> (weakref to the tensor, version, gain)
 
 
 def _kernel_gain(kernel):
     """The HIP kernels hold the binomial weights as constants; a ``kernel`` argument (reference signature) must be
-    gain * gauss_kernel().  The values are read back ONCE per tensor (id, version): reference-style callers pass a
-    fresh gauss_kernel(device=cuda) per loss call and a host sync per call would stall the stream."""
+    gain * gauss_kernel().  The values are read back ONCE per live tensor object and version: the cache entry holds a weak
+    reference to the tensor it validated, so a different tensor that the caching allocator later places at the same
+    address (reference-style callers build a fresh gauss_kernel(device=cuda) per loss call) is validated again instead
+    of inheriting a stale gain; a host sync per call would stall the stream."""
     if kernel is None:
         return 1.0
     if kernel.dim() != 4 or kernel.shape[-2:] != (5, 5):
         raise NotImplementedError('only the 5x5 binomial gauss_kernel() is implemented')
-    key = (kernel.data_ptr(), kernel._version, kernel.shape[0])
-    gain = _checked_kernels.get(key)
-    if gain is None:
-        k = kernel.detach().float().cpu()
-        gain = float(k[0, 0, 2, 2]) * 256. / 36.
-        ref = gauss_kernel(channels=k.shape[0]) * gain
-        if k.shape[1] != 1 or gain == 0. or (k - ref).abs().max() > 1e-6 * abs(gain):
-            raise NotImplementedError('only (a multiple of) the 5x5 binomial gauss_kernel() is implemented')
-        if len(_checked_kernels) > 64:
-            _checked_kernels.clear()
-        _checked_kernels[key] = gain
+    if getattr(kernel, '_rvsr_gain', None) is not None and kernel._version == 0:
+        return kernel._rvsr_gain
+    hit = _checked_kernels.get(id(kernel))
+    if hit is not None and hit[0]() is kernel and hit[1] == kernel._version:
+        return hit[2]
+    k = kernel.detach().float().cpu()
+    gain = float(k[0, 0, 2, 2]) * 256. / 36.
+    ref = gauss_kernel(channels=k.shape[0]) * gain
+    if k.shape[1] != 1 or gain == 0. or (k - ref).abs().max() > 1e-6 * abs(gain):
+        raise NotImplementedError('only (a multiple of) the 5x5 binomial gauss_kernel() is implemented')
+    for key in [key for key, v in _checked_kernels.items() if v[0]() is None]:
+        del _checked_kernels[key]
+    _checked_kernels[id(kernel)] = (weakref.ref(kernel), kernel._version, gain)
     return gain
 
 

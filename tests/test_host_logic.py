@@ -132,3 +132,145 @@ def test_flat_buffers_layout_and_guards():
     assert _pgrad(p0).data_ptr() == fb.grad.data_ptr() + 4 * fb.offset[p0]
     p0.grad = torch.zeros_like(p0)
     assert _pgrad(p0).data_ptr() != fb.grad.data_ptr() + 4 * fb.offset[p0]
+
+
+def test_pgrad_hands_a_home_out_once_per_step():
+    """functional._pgrad: a parameter used by TWO fused operators in one backward must not get the same
+    flat-buffer view twice -- AccumulateGrad has not run between the uses, p.grad is still None, and aliased outputs would turn
+    g1 + g2 into 2 * g_last.  Emulated on CPU with an autograd Function that writes its weight gradient the way the fused
+    operators do."""
+    from realvsr_amd.functional import _pgrad
+    from realvsr_amd.optim import FlatBuffers
+
+    class Scale(torch.autograd.Function):     # y = w * x, gradient of w written into _pgrad's buffer
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x)
+            ctx.w = w
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            gw = _pgrad(ctx.w)
+            gw.copy_(g * x)
+            return g * ctx.w, gw
+
+    w = torch.nn.Parameter(torch.tensor([1., 2., 3., 4.]))
+    fb = FlatBuffers([[w]])
+    fb.zero_grad()
+    x1, x2 = torch.tensor([1., 2., 3., 4.]), torch.tensor([10., 20., 30., 40.])
+    (Scale.apply(x1, w) + Scale.apply(x2, w)).sum().backward()
+    fb.rebind()
+    assert torch.equal(w.grad, x1 + x2)                     # not 2 * x1 (or 2 * x2)
+    assert w.grad.data_ptr() == fb.grad.data_ptr() + 4 * fb.offset[w]
+    # next step: the home can be claimed again; a first use gets the flat view, the second a temporary
+    fb.zero_grad()
+    a, b = _pgrad(w), _pgrad(w)
+    assert a.data_ptr() == fb.grad.data_ptr() + 4 * fb.offset[w] and b.data_ptr() != a.data_ptr()
+    # torch.autograd.grad(): the fused backward wrote into the home but autograd handed the result to the caller, not to
+    # p.grad -- rebind() must not present that as this step's gradient
+    fb.zero_grad()
+    (gw,) = torch.autograd.grad(Scale.apply(x1, w).sum(), [w])
+    assert torch.equal(gw, x1) and w.grad is None
+    fb.rebind()
+    assert float(w.grad.abs().sum()) == 0
+
+
+def test_gradsink_refuses_concat_convs():
+    from realvsr_amd import functional as RF
+    x = torch.zeros(1, 2, 4, 4)
+    conv = torch.nn.Conv2d(4, 2, 3, padding=1)
+    with pytest.raises((RuntimeError, NotImplementedError)) as e:
+        RF.conv2d(x, conv, x2=x, sink=RF.GradSink())
+    # the sink check comes first (a CPU tensor would raise NotImplementedError after it)
+    assert 'GradSink' in str(e.value)
+
+
+def test_gauss_kernel_gain_cache_is_not_fooled_by_address_reuse():
+    from realvsr_amd import util
+    k = util.gauss_kernel(channels=3)
+    assert util._kernel_gain(k) == 1.0 and util._kernel_gain(4 * k) == 4.0
+    other = k.clone()
+    assert util._kernel_gain(other) == 1.0
+    other[0, 0, 0, 0] = 7.0                                   # same object, new version: validated again
+    with pytest.raises(NotImplementedError):
+        util._kernel_gain(other)
+    k.mul_(2.0)                                                # the tag of gauss_kernel() only holds for version 0
+    assert util._kernel_gain(k) == 2.0
+
+
+def test_cutblur_box_follows_python_slice_semantics():
+    """with alpha near 0 the reference's cut_ratio can go negative; [cy:cy+ch] then wraps like a python slice.
+    And the resolution check precedes every RNG draw (data/augments_video_allpair.py:55-56)."""
+    import numpy as np
+    from realvsr_amd import augment
+    plan = augment.AugPlan()
+    np.random.seed(3)
+    state = np.random.get_state()
+    with pytest.raises(ValueError):
+        augment._draw_cutblur(plan, (1, 2, 3, 8, 8), 1.0, 0.7, size1=(1, 2, 3, 4, 4))
+    assert all(np.array_equal(a, b) for a, b in zip(state[1:3], np.random.get_state()[1:3]))   # nothing drawn
+    # brute-force the reference's arithmetic for a negative ratio and compare the box with an actual slice assignment
+    for seed in range(40):
+        np.random.seed(seed)
+        size = (1, 2, 3, 9, 11)
+        plan = augment.AugPlan()
+        augment._draw_cutblur(plan, size, 1.0, 0.004)
+        np.random.seed(seed)
+        np.random.rand(1)
+        ratio = np.random.randn() * 0.01 + 0.004
+        h, w = size[2], size[3]
+        ch, cw = int(h * ratio), int(w * ratio)
+        cy, cx = np.random.randint(0, h - ch + 1), np.random.randint(0, w - cw + 1)
+        m = np.zeros(size[-2:], bool)
+        m[cy:cy + ch, cx:cx + cw] = True
+        y0, y1, x0, x1 = plan.box
+        m2 = np.zeros(size[-2:], bool)
+        m2[y0:y1, x0:x1] = True
+        assert np.array_equal(m, m2), (seed, plan.box, (cy, ch, cx, cw))
+
+
+def test_flat_adam_skips_missing_grads_and_resets_state():
+    """torch.optim.Adam semantics the dense flat update must keep: parameters whose grad is None do not move,
+    and clearing optimizer.state (MultiStepLR_Restart(clear_state=True)) restarts the moments.  The kernel launch itself needs a
+    GPU; here the arithmetic is replaced by torch's so that the host logic around it is what is tested."""
+    from realvsr_amd import optim, functional as RF
+
+    def adam_cpu(param, grad, m, v, step_size, b1, b2, eps, wd, bc2s):
+        g = grad + wd * param if wd else grad
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        param.addcdiv_(m, v.sqrt() / bc2s + eps, value=-step_size)
+
+    orig = RF.adam_step_
+    RF.adam_step_ = adam_cpu
+    try:
+        torch.manual_seed(0)
+        a, b = torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(7))
+        ra, rb = torch.nn.Parameter(a.detach().clone()), torch.nn.Parameter(b.detach().clone())
+        opt, ref = optim.FlatAdam([a, b], lr=1e-2, weight_decay=0.1), torch.optim.Adam([ra, rb], lr=1e-2, weight_decay=0.1)
+        for it in range(4):
+            opt.zero_grad()
+            ref.zero_grad(set_to_none=True)
+            (a * a).sum().backward()
+            (ra * ra).sum().backward()
+            if it != 1:                        # step 1: b gets no gradient at all
+                (b * 3).sum().backward()
+                (rb * 3).sum().backward()
+            b_before, m_before = b.detach().clone(), opt.state[b]['exp_avg'].clone() if b in opt.state else None
+            opt.step()
+            ref.step()
+            assert torch.allclose(a, ra, atol=1e-6), it
+            if it <= 1:
+                # (after a skipped step torch's PER-PARAMETER step count lags the group's; FlatAdam counts per group -- documented)
+                assert torch.allclose(b, rb, atol=1e-6), it
+            if it == 1:
+                assert torch.equal(b.detach(), b_before) and torch.equal(opt.state[b]['exp_avg'], m_before)
+            if it == 2:                        # restart: the reference's scheduler empties optimizer.state
+                from collections import defaultdict
+                opt.state = defaultdict(dict)
+                ref.state = defaultdict(dict)
+        assert float(opt.state[a]['step']) == 1.0
+    finally:
+        RF.adam_step_ = orig
