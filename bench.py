@@ -113,21 +113,22 @@ def make_batch(B, N, H, W, device, rank=0):
 
 
 class DcnTimer:
-    """HIP events around every fused-DCN forward launch on the launching (current) stream."""
+    """HIP events around every fused-DCN forward (and backward) launch on the launching (current) stream."""
 
     def __init__(self):
-        self.events, self.bytes = [], 0.0
+        self.events, self.bytes, self.bwd_events = [], 0.0, []
 
     def install(self):
         from realvsr_amd import functional as RF
-        orig = RF._lib.lib().rvsr_dcn_pack_forward
+        real = RF._lib.lib()
+        orig_f, orig_b = real.rvsr_dcn_pack_forward, real.rvsr_dcn_pack_backward
         timer = self
 
         def timed(*a):
             # a: input, weight, bias, om, output, B, C, H, W, Co, stride, pad, dil, dg, act, slope, ws, ws_bytes, stream
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            rc = orig(*a)
+            rc = orig_f(*a)
             e.record()
             B, C, H, W, Co, stride, pad, dil = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
             Ho = (H + 2 * pad - (2 * dil + 1)) // stride + 1
@@ -136,7 +137,15 @@ class DcnTimer:
             timer.bytes += 4.0 * (C * H * W + (216 + Co) * Ho * Wo) * B + 4.0 * Co * C * 9
             return rc
 
-        _Proxy.wrap(RF, 'rvsr_dcn_pack_forward', timed)
+        def timed_bwd(*a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = orig_b(*a)
+            e.record()
+            timer.bwd_events.append((s, e))
+            return rc
+
+        _Proxy.wrap(RF, {'rvsr_dcn_pack_forward': timed, 'rvsr_dcn_pack_backward': timed_bwd})
 
     def uninstall(self):
         from realvsr_amd import functional as RF
@@ -146,20 +155,24 @@ class DcnTimer:
         ms = sum(s.elapsed_time(e) for s, e in self.events)
         return len(self.events), ms, self.bytes
 
+    def backward_ms(self):
+        return sum(s.elapsed_time(e) for s, e in self.bwd_events)
+
 
 class _Proxy:
-    """Minimal proxy so one C-ABI symbol can be intercepted without touching the library object."""
+    """Minimal proxy so C-ABI symbols can be intercepted without touching the library object."""
 
-    def __init__(self, lib, name, fn):
-        self.__dict__['_lib'], self.__dict__['_name'], self.__dict__['_fn'] = lib, name, fn
+    def __init__(self, lib, fns):
+        self.__dict__['_lib'], self.__dict__['_fns'] = lib, fns
 
     def __getattr__(self, k):
-        return self._fn if k == self._name else getattr(self._lib, k)
+        fn = self._fns.get(k)
+        return fn if fn is not None else getattr(self._lib, k)
 
     @staticmethod
-    def wrap(RF, name, fn):
+    def wrap(RF, fns):
         real = RF._lib.lib()
-        RF._lib._lib = _Proxy(real, name, fn)
+        RF._lib._lib = _Proxy(real, fns)
         _Proxy._real = real
 
     @staticmethod
@@ -193,6 +206,75 @@ def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
             'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'mfma_passes_per_product': passes, 'f32_equivalent': round(flop / (ms * 1e-3) / 1e12, 1),
             'avg_launch_ms': round(ms, 4), 'traffic': None}
+
+
+class _Snapshot:
+    """Parameters + Adam state of the model, to put back after an excursion (offset rescale, other GEMM mode)."""
+
+    def __init__(self, model):
+        o = model.optimizer_G
+        self.o = o
+        self.param, self.m1, self.m2 = o.buffers.param.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone()
+        self.steps = list(o._steps)
+
+    def restore(self):
+        o = self.o
+        o.buffers.param.copy_(self.param)
+        o.exp_avg.copy_(self.m1)
+        o.exp_avg_sq.copy_(self.m2)
+        o._steps = list(self.steps)
+        for t, v in zip(o._step_t, self.steps):
+            t.fill_(float(v))
+
+
+def timed_steps(model, n, first_step):
+    """1 untimed + n timed optimizer steps with the DCN timers installed: (ms/step, DCN fwd frac of the HBM peak, DCN bwd ms/step)."""
+    model.optimize_parameters(first_step, log=False)
+    timer = DcnTimer()
+    timer.install()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        model.optimize_parameters(first_step + 1 + i, log=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.uninstall()
+    nl, kms, kbytes = timer.result()
+    frac = kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None
+    return 1e3 * dt / n, frac, timer.backward_ms() / n
+
+
+def offset_sweep(model, x, first_step, pxs=(1.0, 3.0), steps=3):
+    """SURVEY.md 8d "second large-motion set", on the driver-timed line: the same step with every conv_offset_mask rescaled to a
+    mean |offset| of P px (i.i.d. per pixel: harsher than trained, spatially smooth fields), 1 untimed + `steps` timed
+    steps each, parameters and optimizer state restored afterwards.  dcn_bwd_ms = HIP-event time of the fused DCN backward
+    calls (input/offset/mask gradient + weight gradient kernels) per step."""
+    out = {}
+    snap = _Snapshot(model)
+    for P in pxs:
+        offset_stats(model.netG, x, P)
+        ms, frac, bwd = timed_steps(model, steps, first_step)
+        st = offset_stats(model.netG, x)
+        l1 = st.get('pcd_align.L1_dcnpack', (None, None))
+        out['%gpx' % P] = {'ms_per_step': round(ms, 3), 'dcn_fwd_frac': None if frac is None else round(frac, 4),
+                           'dcn_bwd_ms': round(bwd, 3), 'steps': steps,
+                           'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3)}
+        snap.restore()
+    return out
+
+
+def f32_mode_step(model, first_step, steps=2):
+    """The same step in the exact-f32 GEMM mode (v_mfma_f32_32x32x2_f32 everywhere), 1 untimed + `steps` timed."""
+    from realvsr_amd import _lib as rlib
+    snap = _Snapshot(model)
+    old = rlib.get_gemm_mode()
+    rlib.set_gemm_mode('f32')
+    try:
+        ms, _, _ = timed_steps(model, steps, first_step)
+    finally:
+        rlib.set_gemm_mode(old)
+        snap.restore()
+    return round(ms, 3)
 
 
 def cpu_baseline(args):
@@ -264,6 +346,7 @@ def main():
     ap.add_argument('--offset-px', type=float, default=None,
                     help='rescale every conv_offset_mask so that the mean |offset| of its DCN is this many pixels')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the post-run offset sweep and the f32-mode step')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -327,6 +410,8 @@ def main():
     for i in range(args.warmup):
         model.optimize_parameters(i + 1, log=False)
     off = offset_stats(model.netG, x) if rank == 0 else {}
+    if model.reducer is not None:
+        model.reducer.reset_stats()
     timer = DcnTimer()
     timer.install()
     fence()
@@ -337,6 +422,21 @@ def main():
     dt = time.perf_counter() - t0
     timer.uninstall()
     loss = model.loss_terms['l_pix']
+    allreduce = None
+    if world > 1:
+        # every rank must hold bit-identical parameters after the last step (same averaged gradients, same Adam arithmetic)
+        probe = model.optimizer_G.buffers.param.double().sum()
+        lo, hi = probe.clone(), probe.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert lo.item() == hi.item(), 'ranks diverged: parameters differ after %d steps' % (args.warmup + args.steps)
+        r = model.reducer
+        allreduce = {'buckets': len(r.buckets), 'bytes': 4 * r.buffers.numel, 'bucket_bytes': [4 * (e - s) for s, e in r.buckets],
+                     'issued_during_backward': r.stats_issued_in_backward, 'exposed_ms': round(r.exposed_ms(), 3),
+                     'backend': backend, 'params_identical_after_last_step': True,
+                     'note': 'exposed_ms = stream time between entering finish() and the last bucket being ready, per step, '
+                             'rank 0, averaged over the timed steps; issued_during_backward = buckets whose all-reduce was '
+                             'enqueued from a gradient hook, i.e. before backward returned (last step)'}
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -390,9 +490,17 @@ def main():
                          'frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
                          'traffic': traffic, 'traffic_source': traffic_source, 'launches': nl,
                          'avg_launch_ms': round(kms / max(nl, 1), 4),
-                         'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1))},
+                         'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1)),
+                         'dcn_bwd_ms_per_step': round(timer.backward_ms() / max(args.steps, 1), 3)},
         }
+        if allreduce is not None:
+            line['allreduce'] = allreduce
         line['roofline_conv'] = conv_roofline(model.netG, B * N, args.nf, H, W, gemm_mode)
+        if world == 1 and not args.no_sweep and args.offset_px is None:
+            nxt = args.warmup + args.steps + 1
+            line['offset_sweep'] = offset_sweep(model, x, nxt)
+            if gemm_mode == 'bf16x3':
+                line['f32_mode_ms_per_step'] = f32_mode_step(model, nxt)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

@@ -62,9 +62,22 @@ class BucketedGradAllReduce:
         self._pending = list(self._need)
         self._next = 0          # next bucket to issue (strictly ascending on every rank)
         self._works = []
+        self.reset_stats()
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+
+    def reset_stats(self):
+        """Evidence for the scaling run (bench.py `allreduce`): how many buckets left during backward, and how long the
+        compute stream waited for the collectives once backward had finished."""
+        self.stats_issued_in_backward = 0
+        self._exposed = []      # (event at finish() entry, event after the last wait) per step
+
+    def exposed_ms(self):
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
     def zero_grad(self):
         self.buffers.zero_grad()
@@ -87,6 +100,11 @@ class BucketedGradAllReduce:
         """Wait for the in-flight buckets and turn the sums into means. Call before optimizer.step()."""
         if self.world == 1:
             return
+        self.stats_issued_in_backward = self._next
+        ev = None
+        if self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self.buffers.rebind()
         self.buffers.check_bound()
         for b in range(self._next, len(self.buckets)):   # buckets holding parameters that got no gradient this step
@@ -94,6 +112,11 @@ class BucketedGradAllReduce:
         self._issue_ready()
         for w in self._works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
+            if len(self._exposed) > 64:
+                del self._exposed[:32]
         self.flat.mul_(1.0 / self.world)
         self._works = []
 
