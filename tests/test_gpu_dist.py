@@ -121,3 +121,24 @@ def test_bench_self_launches_n_ranks():
     rec = json.loads(line)
     assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 2 and rec['config']['parallelism'] == 'sequence-dp2'
     assert rec['value'] > 0 and rec['roofline']['launches'] == 2 * 4
+    # evidence for the day the scaling run happens: what was all-reduced, how much of it during backward, what stayed exposed
+    ar = rec['allreduce']
+    assert ar['buckets'] >= 1 and ar['bytes'] == sum(ar['bucket_bytes']) and ar['params_identical_after_last_step'] is True
+    assert 0 <= ar['issued_during_backward'] <= ar['buckets'] and ar['exposed_ms'] >= 0.0
+
+
+def test_bench_line_carries_offset_sweep_and_f32_step():
+    """The driver-timed line (N = 1) reports the large-motion set and the exact-f32 step next to the headline (VERDICT r2 #3)."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch', '1',
+                          '--height', '32', '--width', '48', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert set(rec['offset_sweep']) == {'1px', '3px'}
+    for k, v in rec['offset_sweep'].items():
+        assert v['ms_per_step'] > 0 and v['dcn_bwd_ms'] > 0 and 0 < v['dcn_fwd_frac'] < 1
+        assert abs(v['offset_abs_mean_px'] - float(k[:-2])) < 0.2 * float(k[:-2])
+    assert rec['f32_mode_ms_per_step'] > 0 and rec['roofline']['dcn_bwd_ms_per_step'] > 0
+    assert 'allreduce' not in rec
