@@ -228,7 +228,9 @@ class _Snapshot:
 
 
 def timed_steps(model, n, first_step):
-    """1 untimed + n timed optimizer steps with the DCN timers installed: (ms/step, DCN fwd frac of the HBM peak, DCN bwd ms/step)."""
+    """2 untimed + n timed optimizer steps with the DCN timers installed: (ms/step, DCN fwd frac of the HBM peak, DCN bwd ms/step).
+    (Two untimed steps: the first one after a change of offsets / GEMM mode re-sizes workspaces and allocator pools.)"""
+    model.optimize_parameters(first_step, log=False)
     model.optimize_parameters(first_step, log=False)
     timer = DcnTimer()
     timer.install()
@@ -246,7 +248,7 @@ def timed_steps(model, n, first_step):
 
 def offset_sweep(model, x, first_step, pxs=(1.0, 3.0), steps=3):
     """SURVEY.md 8d "second large-motion set", on the driver-timed line: the same step with every conv_offset_mask rescaled to a
-    mean |offset| of P px (i.i.d. per pixel: harsher than trained, spatially smooth fields), 1 untimed + `steps` timed
+    mean |offset| of P px (i.i.d. per pixel: harsher than trained, spatially smooth fields), 2 untimed + `steps` timed
     steps each, parameters and optimizer state restored afterwards.  dcn_bwd_ms = HIP-event time of the fused DCN backward
     calls (input/offset/mask gradient + weight gradient kernels) per step."""
     out = {}
@@ -264,7 +266,7 @@ def offset_sweep(model, x, first_step, pxs=(1.0, 3.0), steps=3):
 
 
 def f32_mode_step(model, first_step, steps=2):
-    """The same step in the exact-f32 GEMM mode (v_mfma_f32_32x32x2_f32 everywhere), 1 untimed + `steps` timed."""
+    """The same step in the exact-f32 GEMM mode (v_mfma_f32_32x32x2_f32 everywhere), 2 untimed + `steps` timed."""
     from realvsr_amd import _lib as rlib
     snap = _Snapshot(model)
     old = rlib.get_gemm_mode()

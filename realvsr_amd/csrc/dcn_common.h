@@ -97,4 +97,8 @@ int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g
 size_t rvsr_dcn_bwdin_auto_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                                float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);
+// fifth-generation input / offset / mask gradient (dcn5_kernels.hip): shared f64 LDS window; halo < 0 = chosen on the device
+size_t rvsr_dcn_bwdin5_workspace_bytes(int Co, int C);
+int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1);
 extern int rvsr_g_gemm_mode;

@@ -429,7 +429,9 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     const int gy = (channels_out + 63) / 64, gz = (channels + DCN_CC - 1) / DCN_CC;
     const size_t Q = 8 * (size_t)bww_P(ntiles, gy, gz);
     const size_t a = sizeof(float) * Q * ((size_t)channels_out * channels * 9 + channels_out);
-    const size_t b2 = rvsr_dcn_bwdin_auto_workspace_bytes(channels_out, channels);   // both weight images + the probe counter
+    size_t b2 = rvsr_dcn_bwdin_auto_workspace_bytes(channels_out, channels);   // both weight images + the probe counter
+    const size_t b5 = rvsr_dcn_bwdin5_workspace_bytes(channels_out, channels);
+    if (b5 > b2) b2 = b5;
     return a > b2 ? a : b2;
 }
 
@@ -445,8 +447,10 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
         if (rvsr_g_gemm_mode == 0) {
-            static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 5; }();  // developer A/B switch
-            if (gen >= 5) rc2 = rvsr_launch_dcn_bwdin_auto(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
+            static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 6; }();  // developer A/B switch
+            static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
+            if (gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo);
+            if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 5) rc2 = rvsr_launch_dcn_bwdin_auto(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 3)
                 rc2 = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
             if (rc2 == RVSR_ERR_UNSUPPORTED)
