@@ -372,325 +372,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
 }
 
 // ------------------------------------------------------------------------------------------
-// 3x3 / stride-1 forward (and data gradient), double-buffered with two ping-pong wave groups: ONE workgroup of 8
-// waves per CU, a 16x32-pixel tile, two LDS buffers for (input chunk, weight chunk).
-//
-// The timeline of conv_fwd2_kernel (tools/conv_timeline.py) showed the MFMA phases at ~1/3 of a workgroup's time,
-// the rest being staging phases and barriers; ablations showed "MFMA + LDS commit" and "global loads + stores" each
-// taking ~0.45 ms of a 0.74 ms launch, i.e. barely overlapping.  Here the work is a flat sequence of stages
-// q = (tile, 16-channel chunk) and time is cut into slots separated by one barrier each.  Waves 0-3 (group A) run the
-// MFMA loop of stage q in slot 2q and do staging work in slot 2q+1; waves 4-7 (group B), which share the SIMDs with
-// them, do staging in slot 2q and MFMA in slot 2q+1.  A staging slot writes the wave's share of stage q+1 (loaded two
-// slots earlier into registers, converted to bf16 hi/lo) to the other LDS buffer and issues the global loads of stage
-// q+2.  So every SIMD always has one wave issuing MFMAs and one wave doing VALU / memory work.
-//   buffer safety: stage q+1 is written in slots 2q (B) and 2q+1 (A) into buffer (q+1)&1, last read by MFMA(q-1) in
-//   slots 2q-2 / 2q-1; it is read by MFMA(q+1) in slots 2q+2 / 2q+3.
-template <int MT, bool ACT_IN, bool VEC>
-__global__ __launch_bounds__(512, 2) void conv_fwd3_kernel(const ConvFwdParams p) {
-    constexpr int KS = 3, T = 9, PAD = 1, NW = 8, TH = 2 * NW, TW = 32, NTHR = NW * 64;
-    constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
-    constexpr int MP = MT * 32, NOCT = 2, NPOS = IH * IW, NX = NOCT * NPOS;
-    constexpr int WVEC = T * NOCT * MP;  // 16-byte vectors per weight part (hi or lo)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16x8* xs_base = reinterpret_cast<bf16x8*>(smem_raw);                // [2 buffers][hi|lo][NX]
-    bf16x8* ws_base = xs_base + 2 * 2 * NX;                               // [2 buffers][hi|lo][WVEC]
-    float* bias_base = reinterpret_cast<float*>(ws_base + 2 * 2 * WVEC);  // [4][MP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int grp = wave >> 2;  // 0: MFMA in even slots, 1: MFMA in odd slots
-    const TView& va = p.in.a;
-    const TView& vb = p.in.b;
-    const int C1 = va.C, Ctot = va.C + vb.C;
-    const int nchunks = (Ctot + 15) / 16;
-
-    // persistent schedule as in conv_fwd2_kernel: 8 contiguous item ranges, one per XCD
-    const unsigned nmb = (p.Co + MP - 1) / MP, nty = (p.Hout + TH - 1) / TH;
-    const unsigned items = p.ntx * nty * nmb * p.B;
-    const unsigned xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, nwq = (gridDim.x + 7 - xcd) >> 3;
-    const unsigned q8 = items >> 3, r8 = items & 7;
-    const unsigned range0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const unsigned range1 = range0 + q8 + (xcd < r8 ? 1 : 0);
-    const unsigned S0 = range0 + wq;
-    if (S0 >= range1) return;
-    const int ntile = (int)((range1 - S0 + nwq - 1) / nwq);
-    const int Q = ntile * nchunks;
-
-    struct Tile { int x0, y0, mb, b; };
-    auto tile_of = [&](int k) {
-        const unsigned S = S0 + (unsigned)k * nwq;
-        Tile t;
-        const unsigned u = S % (p.ntx * nty);
-        t.x0 = (int)(u % p.ntx) * TW;
-        t.y0 = (int)(u / p.ntx) * TH;
-        t.mb = (int)((S / (p.ntx * nty)) % nmb);
-        t.b = (int)(S / (p.ntx * nty * nmb));
-        return t;
-    };
-
-    // Staging.  VEC (stored width % 4 == 0, 16-byte aligned planes, plain view): one item = (octet, tile row, group of
-    // 4 pixels starting at x0 - 4 + 4g), fetched with 8 aligned 16-byte loads (one per channel) -- a third of the
-    // load instructions and address arithmetic of the scalar path.  The 10 groups of a row cover 40 pixels of which
-    // the tile uses 34 (groups 0 and 9 contribute one pixel each).  All loads are unconditional (clamped addresses,
-    // validity applied at the LDS write), see conv_fwd2_kernel.
-    constexpr int NG = 10;
-    constexpr int NIT = VEC ? 1 : (NX + NTHR - 1) / NTHR;  // input items per thread
-    constexpr int NWV = (2 * WVEC + NTHR - 1) / NTHR;      // weight vectors per thread
-    constexpr int NV = VEC ? 4 : 1;                        // pixels per item
-    int it_oc[NIT], it_sp[NIT], it_dst[NIT];
-    bool it_pos_ok[NIT];
-    auto item_geom = [&](const Tile& t) {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            if (VEC) {
-                const bool live = tid < NOCT * IH * NG;
-                const int it = live ? tid : 0;
-                const int oc = it / (IH * NG), rem = it - oc * (IH * NG);
-                const int r = rem / NG, g = rem - r * NG;
-                const int gy = t.y0 - PAD + r, gx = t.x0 - 4 + 4 * g;
-                it_oc[i] = oc;
-                it_pos_ok[i] = live && gy >= 0 && gy < va.Hv && gx >= 0 && gx < va.Wv;
-                const int gyc = gy < 0 ? 0 : (gy >= va.Hv ? va.Hv - 1 : gy), gxc = gx < 0 ? 0 : (gx >= va.Wv ? va.Wv - 4 : gx);
-                it_sp[i] = gyc * va.Ws + gxc;
-                it_dst[i] = live ? (oc * IH + r) * IW + 4 * g - 3 : -100;  // LDS slot of the group's first pixel
-            } else {
-                const int it_raw = tid + i * NTHR;
-                const bool live = it_raw < NX;
-                const int it = live ? it_raw : 0;
-                const int oc = it / NPOS, pos = it - oc * NPOS;
-                const int r = pos / IW, s = pos - r * IW;
-                const int gy = t.y0 - PAD + r, gx = t.x0 - PAD + s;
-                it_oc[i] = oc;
-                bool ok = live && gy >= 0 && gx >= 0 && gy < va.Hv && gx < va.Wv;
-                const int gyc = gy < 0 ? 0 : (gy >= va.Hv ? va.Hv - 1 : gy), gxc = gx < 0 ? 0 : (gx >= va.Wv ? va.Wv - 1 : gx);
-                if (va.mode == 1) {  // zero-insert view: only even (y, x) carry data
-                    const int ys = gyc >> 1, xs = gxc >> 1;
-                    ok = ok && !((gyc | gxc) & 1) && ys < va.Hs && xs < va.Ws;
-                    it_sp[i] = (ys < va.Hs ? ys : 0) * va.Ws + (xs < va.Ws ? xs : 0);
-                } else {
-                    it_sp[i] = va.mode == 0 ? gyc * va.Ws + gxc : (2 * gyc) * va.Ws + 2 * gxc;
-                }
-                it_pos_ok[i] = ok;
-                it_dst[i] = live ? it : -100;
-            }
-        }
-    };
-    float vin[NIT][8][NV];
-    float ain[ACT_IN ? NIT : 1][8][NV];
-    int nvalid[NIT];
-    bf16x8 wv[NWV];
-    auto issue_loads = [&](const Tile& t, int chunk) {
-        const bf16x8* src = reinterpret_cast<const bf16x8*>(p.wpack) + ((size_t)t.mb * nchunks + chunk) * 2 * WVEC;
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int e = tid + i * NTHR;
-            wv[i] = src[e < 2 * WVEC ? e : 0];
-        }
-        const int c0 = chunk * 16;
-        const size_t hw = (size_t)va.Hs * va.Ws;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int cb = c0 + it_oc[i] * 8;
-            const bool inb = it_pos_ok[i] && cb < Ctot;
-            if (VEC || va.mode != 2) {  // (uniform branch)
-                const bool second = inb && cb >= C1;  // octets never straddle the two inputs (C1 % 8 == 0)
-                const float* bp = second ? vb.p : va.p;
-                const float* ap = va.act;
-                const int Cb = second ? vb.C : va.C;
-                const int cl = inb ? (second ? cb - C1 : cb) : 0;
-                nvalid[i] = inb ? (Cb - cl < 8 ? Cb - cl : 8) : 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int cj = cl + j < Cb ? cl + j : Cb - 1;
-                    const size_t idx = ((size_t)t.b * Cb + cj) * hw + it_sp[i];
-                    if (VEC) {
-                        const float4 q = *reinterpret_cast<const float4*>(bp + idx);
-                        vin[i][j][0] = q.x; vin[i][j][NV > 1 ? 1 : 0] = q.y; vin[i][j][NV > 2 ? 2 : 0] = q.z; vin[i][j][NV > 3 ? 3 : 0] = q.w;
-                        if (ACT_IN) {
-                            const float4 a = *reinterpret_cast<const float4*>(ap + idx);
-                            ain[i][j][0] = a.x; ain[i][j][NV > 1 ? 1 : 0] = a.y; ain[i][j][NV > 2 ? 2 : 0] = a.z; ain[i][j][NV > 3 ? 3 : 0] = a.w;
-                        }
-                    } else {
-                        vin[i][j][0] = bp[idx];
-                        if (ACT_IN) ain[i][j][0] = ap[idx];
-                    }
-                }
-            } else {  // mode 2: pixel-unshuffle view, virtual channel c -> stored (c>>2, 2y+((c>>1)&1), 2x+(c&1))
-                const int cbc = inb ? cb : 0;
-                const size_t base = ((size_t)t.b * (va.C >> 2) + (cbc >> 2)) * hw + it_sp[i];
-                nvalid[i] = inb ? 8 : 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const size_t idx = base + (j >> 2) * hw + ((j >> 1) & 1) * va.Ws + (j & 1);
-                    vin[i][j][0] = va.p[idx];
-                    if (ACT_IN) ain[i][j][0] = va.act[idx];
-                }
-            }
-        }
-    };
-    auto commit = [&](int buf) {
-        bf16x8* xs_hi = xs_base + buf * 2 * NX;
-        bf16x8* xs_lo = xs_hi + NX;
-        bf16x8* ws = ws_base + buf * 2 * WVEC;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            // validity as AND masks computed once per item: a compare + v_cndmask per value goes through VCC and
-            // serialises the (single) staging wave of the SIMD
-            unsigned vm[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) vm[j] = j < nvalid[i] ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int e = 0; e < NV; ++e) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float x = ACT_IN ? vin[i][j][e] * (ain[i][j][e] > 0.f ? 1.f : va.slope) : vin[i][j][e];
-                    v[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & vm[j]);
-                }
-                bf16x8 h8, l8;
-                split8(v, h8, l8);
-                const int dst = it_dst[i] + e;
-                bool ok = dst >= 0;
-                if (VEC) {  // groups 0 and 9 straddle the tile's 34-pixel row
-                    const int s = 4 * (tid % NG) - 3 + e;
-                    ok = ok && s >= 0 && s < IW;
-                }
-                if (ok) {
-                    xs_hi[dst] = h8;
-                    xs_lo[dst] = l8;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int e = tid + i * NTHR;
-            if (e < 2 * WVEC) ws[e] = wv[i];
-        }
-    };
-    // bias of tile k lives in slot k & 3: tiles k-1 .. k+1 can be alive at once when a tile is a single stage
-    Tile itile = tile_of(0);
-    auto issue_stage = [&](int q) {
-        if (q >= Q) return;
-        const int k = q / nchunks, ch = q - k * nchunks;
-        if (ch == 0) {
-            itile = tile_of(k);
-            item_geom(itile);
-            if (tid < MP) {
-                const int o = itile.mb * MP + tid;
-                bias_base[(k & 3) * MP + tid] = (p.bias != nullptr && o < p.Co) ? p.bias[o] : 0.f;
-            }
-        }
-        issue_loads(itile, ch);
-    };
-
-    STAMP(60);
-    issue_stage(0);
-    commit(0);
-    issue_stage(1);
-    __syncthreads();
-
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        acc[m][0] = zero16();
-        acc[m][1] = zero16();
-    }
-    for (int t = 0; t < 2 * Q; ++t) {
-        STAMP(1 + (t & 7) * 3);
-        if ((t & 1) == grp) {
-            // ---- MFMA slot: stage q from buffer q & 1
-            const int q = (t - grp) >> 1;
-            const int buf = q & 1;
-            const bf16x8* xs_hi = xs_base + buf * 2 * NX;
-            const bf16x8* xs_lo = xs_hi + NX;
-            const bf16x8* ws_hi = ws_base + buf * 2 * WVEC;
-            const bf16x8* ws_lo = ws_hi + WVEC;
-            // operand fragments are fetched exactly one tap ahead (two register slots); the scheduling fences keep
-            // hipcc from hoisting more LDS reads than that
-            bf16x8 ah[2][MT], al[2][MT], bh[2][2], bl[2][2];
-            auto fetch = [&](int tap, int slot) {
-                const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ah[slot][m] = ws_hi[(tap * NOCT + hi) * MP + m * 32 + lo];
-                    al[slot][m] = ws_lo[(tap * NOCT + hi) * MP + m * 32 + lo];
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int idx = (hi * IH + wave * 2 + n + dy) * IW + lo + dx;
-                    bh[slot][n] = xs_hi[idx];
-                    bl[slot][n] = xs_lo[idx];
-                }
-            };
-            fetch(0, 0);
-#pragma unroll
-            for (int tap = 0; tap < T; ++tap) {
-                const int sl = tap & 1;
-                if (tap + 1 < T) fetch(tap + 1, sl ^ 1);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bh[sl][n], acc[m][n]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bl[sl][n], acc[m][n]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[sl][m], bh[sl][n], acc[m][n]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int k = q / nchunks;
-            if (q - k * nchunks == nchunks - 1) {  // last chunk of tile k: epilogue, fresh accumulators
-                const Tile cur = tile_of(k);
-                const float* bias_s = bias_base + (k & 3) * MP;
-                if (p.ps)
-                    conv2_epilogue<MT, 3>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
-                else if (p.out2 != nullptr)
-                    conv2_epilogue<MT, 2>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
-                else if (p.res != nullptr) {
-                    if (p.vec4) conv2_epilogue_v4<MT, 1>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0, lo, hi);
-                    else conv2_epilogue<MT, 1>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
-                } else {
-                    if (p.vec4) conv2_epilogue_v4<MT, 0>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0, lo, hi);
-                    else conv2_epilogue<MT, 0>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[m][0] = zero16();
-                    acc[m][1] = zero16();
-                }
-            }
-        } else {
-            // ---- staging slot: publish this wave's share of stage q+1, fetch stage q+2
-            const int q = grp == 0 ? (t - 1) >> 1 : t >> 1;
-#ifdef RVSR_TIMELINE
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(40 + (t & 7) * 2);
-#endif
-            if (q + 1 < Q) commit((q + 1) & 1);
-#ifdef RVSR_TIMELINE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(41 + (t & 7) * 2);
-#endif
-            issue_stage(q + 2);
-        }
-        STAMP(2 + (t & 7) * 3);
-        __syncthreads();
-        STAMP(3 + (t & 7) * 3);
-    }
-    STAMP(61);
-#ifdef RVSR_TIMELINE
-    if (blockIdx.x == 77 && tid == 0) rvsr_dbg[62] = (unsigned long long)Q;
-#endif
-}
-
-// ------------------------------------------------------------------------------------------
-// 3x3 / stride-1 forward (and data gradient), software-pipelined per wave: same tile, LDS image, stage sequence and
-// double buffering as conv_fwd3_kernel, but every wave runs the MFMA loop of every stage and carries its share of the
+// 3x3 / stride-1 forward (and data gradient), software-pipelined per wave: ONE workgroup of 8 waves per CU, a 16x32-pixel
+// tile, a flat sequence of stages (tile, 16-channel chunk) over two LDS buffers (input chunk + weight chunk) with one barrier
+// per stage; every wave runs the MFMA loop of every stage and carries its share of the
 // staging work INSIDE that loop, a slice per tap.  Measured on MI355X: a wave's own VALU / LDS / load instructions
 // issue in the gaps of its MFMA stream (up to ~5 per 32x32x16 MFMA), whereas instructions of the OTHER wave of the
-// SIMD get roughly one issue slot per MFMA (~18 cycles per instruction: conv_fwd3's staging slot, and a variant with
-// dedicated staging waves ran 2x slower).  Registers of stage q+1 are published to LDS during taps 0-3 (inputs) and
+// SIMD get roughly one issue slot per MFMA (~18 cycles per instruction in round 1's ping-pong kernel with dedicated staging
+// slots, removed in round 3; a variant with dedicated staging waves ran 2x slower).  Registers of stage q+1 are published to LDS during taps 0-3 (inputs) and
 // 4-8 (weights) of stage q and refilled at once with the loads of stage q+2, so the staging registers are not doubled.
 // VEC: 0 = scalar staging (any view), 1 = vector staging of a plain view, 2 = vector staging of a pixel-unshuffle view
 template <int MT, bool ACT_IN, int VEC>
@@ -1173,27 +861,6 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
     return RVSR_OK;
 }
 
-template <int MT>
-static int launch_fwd3(const ConvFwdParams& p, hipStream_t st) {
-    constexpr int NX = 2 * 18 * 34, WVEC = 9 * 2 * MT * 32;
-    const size_t lds = (size_t)16 * (2 * 2 * NX + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32;
-    const TView& va = p.in.a;
-    const TView& vb = p.in.b;
-    const bool vec = va.mode == 0 && va.Ws % 4 == 0 && va.Wv == va.Ws &&
-                     ((((uintptr_t)va.p) | ((uintptr_t)va.act) | ((uintptr_t)vb.p)) & 15) == 0;
-    auto k = va.act != nullptr ? (vec ? conv_fwd3_kernel<MT, true, true> : conv_fwd3_kernel<MT, true, false>)
-                               : (vec ? conv_fwd3_kernel<MT, false, true> : conv_fwd3_kernel<MT, false, false>);
-    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd3: cannot reserve %zu B of LDS", lds);
-    const int nty = (p.Hout + 15) / 16;
-    const long items = (long)p.ntx * nty * ((p.Co + MT * 32 - 1) / (MT * 32)) * p.B;
-    dim3 grid((unsigned)(items < 256 ? items : 256), 1, 1);
-    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_fwd3 launch: %s", hipGetErrorString(e));
-    return RVSR_OK;
-}
-
-// p.w = f32 weights; packs them into `workspace`, then runs the bf16x3 kernel
 int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const int Ctot = p.in.a.C + p.in.b.C;
     int mt, ccg, nchunks, nmb;
@@ -1219,14 +886,7 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
         if (mt == 2) return launch_fwd2<KS, S, 2, CCG>(p, st);  \
         return launch_fwd2<KS, S, 4, CCG>(p, st);               \
     } while (0)
-    static int use3 = -1;
-    if (use3 < 0) {
-        const char* e = getenv("RVSR_CONV_FWD");
-        use3 = (e && e[0] == '2') ? 0 : ((e && e[0] == '3') ? 1 : 5);  // developer A/B switch: RVSR_CONV_FWD=2 / 3 select the older kernels
-    }
-    if (ksize == 3 && stride == 1 && use3 == 5) return mt == 1 ? launch_fwd5<1>(p, st) : launch_fwd5<2>(p, st);
-    if (ksize == 3 && stride == 1 && use3) return mt == 1 ? launch_fwd3<1>(p, st) : launch_fwd3<2>(p, st);
-    if (ksize == 3 && stride == 1) DISPATCH2(3, 1, 1);
+    if (ksize == 3 && stride == 1) return mt == 1 ? launch_fwd5<1>(p, st) : launch_fwd5<2>(p, st);
     if (ksize == 3 && stride == 2) DISPATCH2(3, 2, 1);
     DISPATCH2(1, 1, 2);
 #undef DISPATCH2

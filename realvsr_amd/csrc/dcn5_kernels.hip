@@ -33,6 +33,13 @@
 // channels, so lane (pixel, half) owns channels 4*half .. 4*half+3 of four taps per M tile, straight from the accumulators.
 #include "dcn_tile.h"
 
+#ifdef RVSR_TIMELINE_DCN5   // s_memtime stamps of one wave of one workgroup (tools/dcn5_timeline.py)
+__device__ unsigned long long rvsr_dbg_dcn5[256];
+extern "C" int rvsr_debug_read_dcn5(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_dcn5), sizeof(unsigned long long) * 256); }
+#define TS5(i) do { if (blockIdx.x == 77 && blockIdx.z == 1 && threadIdx.x == 192) rvsr_dbg_dcn5[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS5(i) do {} while (0)
+#endif
 #ifndef RVSR_ABL5
 #define RVSR_ABL5 0   // scratch ablation builds (tools/build_variant5.sh): bit mask of deleted ingredients, results wrong by construction
 #endif
@@ -256,18 +263,24 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xoff[k], (unsigned)(c0 + e) * HW4);   // (C % 8 == 0)
     };
+    TS5(0);
     request(0);
+    TS5(1);
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * 8;
         const int g = c0 / d.cpg;
+        if (chunk < 4) TS5(10 + 8 * chunk);
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int it = tid + k * NT;
             if (it < 2 * NPOS) xt[it] = make_float4(xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
         }
+        if (chunk < 4) TS5(11 + 8 * chunk);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA has landed
+        if (chunk < 4) TS5(12 + 8 * chunk);
         __syncthreads();
+        if (chunk < 4) TS5(13 + 8 * chunk);
 
         // fixed-point scale of this chunk (see the header): |contribution| * S <= 0.995 * 2^31 / 2304
         float S, invS;
@@ -293,10 +306,12 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                 acc = mfma_bf16(ah, gl[ks], acc);
                 acc = mfma_bf16(al, gh[ks], acc);
             }
+            if (chunk == 1) TS5(90 + mt);
 #pragma unroll
             for (int tsel = 0; tsel < 4; ++tsel) {
                 const int tap = 4 * mt + tsel;
                 if (tap >= 9) continue;  // uniform
+                if (chunk == 1) TS5(50 + 4 * tap);
                 // lanes without a pixel: zero offset, zero mask (their col_grad is already 0: gOut was read as 0)
                 const float dy = px_ok ? o_dy[tap] : 0.f, dx = px_ok ? o_dx[tap] : 0.f;
                 float m = o_m[tap];
@@ -350,6 +365,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                     gx_s += dxv * t[e];
                 }
                 const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+                if (chunk == 1) TS5(51 + 4 * tap);
                 if (in_tile && !(RVSR_ABL5 & 2)) {   // ---- scatter: 16 LDS integer atomics into the shared window (cells outside the image are dropped by the flush)
                     int* q = gq + pos0;
 #pragma unroll
@@ -361,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                         lds_add_i32(q + e * NPOS + TC + 1, fx_units(w11, ts));
                     }
                 }
+                if (chunk == 1) TS5(52 + 4 * tap);
                 if (far) {
                     float* gp = p.gx + ((size_t)b * d.C + cq) * HW;
 #pragma unroll
@@ -392,8 +409,11 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                 }
             }
         }
+        if (chunk < 4) TS5(14 + 8 * chunk);
         __syncthreads();
+        if (chunk < 4) TS5(15 + 8 * chunk);
         if (chunk + 1 < nchunks) request(chunk + 1);   // (uniform) in flight while the window is flushed
+        if (chunk < 4) TS5(16 + 8 * chunk);
         // ---- flush: wave w owns channel c0 + w; one global atomic per touched cell inside the image (the halos of
         // neighbouring workgroups overlap), cell back to zero for the next chunk
         {
@@ -420,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                 }
             }
         }
+        if (chunk < 4) TS5(17 + 8 * chunk);
         // (the barrier after the next commit orders this flush before the next chunk's atomics)
     }
 }

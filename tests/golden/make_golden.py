@@ -372,6 +372,48 @@ def main_train_step():
     save('train_step', **arrs)
 
 
+def main_train_step_combine():
+    """train_step_combine.npz: the reference's Combine model class (codes/models/VideoSR_AllPair_model_YCbCr_Combine.py:187-221)
+    built through create_model(opt) on CPU and driven for 2 optimize_parameters() steps: l_tot = 1.0 * CharbonnierLoss on all
+    three channels + 0.5 * PyramidLoss(3, 'lap', 'cb') ('edge_criterion: pyr'); per-step l_tot / l_edg, gradient norm of the
+    first step, parameters after the second step, post-step output.  Every op is in-tree => PINNED."""
+    EDVR_arch, loss_mod, util, dc = import_reference()
+    import models
+    net_opt = dict(which_model_G='EDVR', nf=16, nc=3, nframes=3, groups=4, front_RBs=1, back_RBs=1, center=None,
+                   predeblur=False, HR_in=False, w_TSA=True)
+    opt = {'model': 'VideoSR_AllPair_YCbCr_Combine', 'dist': False, 'gpu_ids': None, 'is_train': True, 'scale': 4,
+           'augment': None, 'network_G': dict(net_opt), 'path': {'pretrain_model_G': None, 'strict_load': True},
+           'train': {'pixel_criterion': 'cb', 'pixel_weight': 1.0, 'edge_criterion': 'pyr', 'edge_weight': 0.5,
+                     'feature_criterion': None, 'feature_weight': 0, 'weight_decay_G': 0, 'ft_tsa_only': 0, 'lr_G': 1e-3,
+                     'beta1': 0.9, 'beta2': 0.99, 'lr_scheme': 'MultiStepLR_Restart', 'lr_steps': [1000], 'restarts': None,
+                     'restart_weights': None, 'lr_gamma': 0.5, 'clear_state': None}}
+    torch.manual_seed(9)
+    model = models.create_model(opt)
+    net = model.netG.module if hasattr(model.netG, 'module') else model.netG
+    fill_state_dict(net, 909, offset_std=0.02)     # weights re-created from the seed by the tests (not stored)
+    gen = torch.Generator().manual_seed(91)
+    gt_c = torch.rand(2, 3, 64, 96, generator=gen)
+    GT = torch.zeros(2, 3, 3, 64, 96)
+    GT[:, 1] = gt_c
+    data = {'LQs': torch.rand(2, 3, 3, 16, 24, generator=gen), 'GT': GT}
+    arrs = {'LQs': data['LQs'].numpy(), 'GT_center': gt_c.numpy()}
+    logs = []
+    for step in range(1, 3):
+        model.feed_data(data)
+        model.optimize_parameters(step)
+        log = model.get_current_log()
+        logs.append([log['l_tot'], log['l_edg']])
+        if step == 1:
+            arrs['gnorm1'] = np.float64(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item())
+    arrs['logs'] = np.array(logs, dtype=np.float64)
+    for k, v in net.state_dict().items():
+        arrs['after.' + k] = v.detach().numpy().copy()
+    model.feed_data(data)
+    model.test()
+    arrs['fake_H'] = model.fake_H.numpy().copy()
+    save('train_step_combine', **arrs)
+
+
 def main_config3():
     """edvr_c3.npz: the architecture of BASELINE configs 3-5 (nf128, 7 frames, TSA, x4) through the reference's EDVR at
     32x48 (back_RBs reduced to 2 to keep the CPU run short): output, loss, gradient norm and a few gradients.  Weights
@@ -446,6 +488,8 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if which in ('all', 'train_step'):
         main_train_step()
+    if which in ('all', 'train_step_combine'):
+        main_train_step_combine()
     if which in ('all', 'config3'):
         main_config3()
     if which in ('all', 'losses2'):

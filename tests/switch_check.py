@@ -1,0 +1,63 @@
+"""Parity spot-check run in a SUBPROCESS by tests/test_gpu_switches.py with one developer switch set (the switches are read once
+per process): a fused DCN pack forward + backward against the CPU oracle at three offset scales, and a 3x3 / 1x1 / stride-2
+conv block against float64 torch.  Exit code 0 = all within the op-level bf16x3 tolerance (1e-4 of the tensor's max)."""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+from conftest import rel_err  # noqa: E402
+
+
+def main():
+    import torch.nn.functional as F
+    from oracle.dcn_oracle import modulated_deform_conv as oracle_dcn
+    from realvsr_amd import functional as RF
+    from realvsr_amd.archs.dcn import modulated_deform_conv
+    d = torch.device('cuda:0')
+    worst = 0.0
+    for C, Co, H, W, ostd in ((64, 64, 20, 40, 0.3), (64, 64, 24, 40, 4.0), (128, 128, 12, 40, 7.0), (32, 72, 9, 33, 1.0)):
+        g = torch.Generator().manual_seed(C + H)
+        t = [torch.randn(1, C, H, W, generator=g), torch.randn(1, 144, H, W, generator=g) * ostd, torch.rand(1, 72, H, W, generator=g),
+             torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5), torch.randn(Co, generator=g)]
+        gout = torch.randn(1, Co, H, W, generator=g)
+        ref = [x.clone().requires_grad_(True) for x in t]
+        oracle_dcn(*ref, 1, 1, 1, 1, 8).backward(gout)
+        got = [x.to(d).requires_grad_(True) for x in t]
+        out = modulated_deform_conv(*got, 1, 1, 1, 1, 8)
+        out.backward(gout.to(d))
+        errs = [rel_err(a.grad.cpu(), b.grad) for a, b in zip(got, ref)]
+        errs.append(rel_err(out.detach().cpu(), oracle_dcn(*[x.detach() for x in ref], 1, 1, 1, 1, 8)))
+        print('dcn', C, Co, H, W, ostd, ' '.join('%.1e' % e for e in errs))
+        worst = max(worst, max(errs))
+    for k, s, Ci, Co in ((3, 1, 64, 64), (3, 1, 128, 216), (1, 1, 64, 64), (3, 2, 64, 64)):
+        g = torch.Generator().manual_seed(k * 10 + s)
+        conv = torch.nn.Conv2d(Ci, Co, k, s, k // 2)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (3.0 * Ci ** 0.5))
+            conv.bias.copy_(torch.randn(Co, generator=g) * 0.1)
+        x = torch.randn(2, Ci, 36, 72, generator=g)
+        wr, xr = conv.weight.detach().double().requires_grad_(True), x.double().requires_grad_(True)
+        z = F.conv2d(xr, wr, conv.bias.detach().double(), s, k // 2)
+        yr = F.leaky_relu(z, 0.1)
+        # (away from the activation kink: where the exact pre-activation is within 1e-3 of zero the derivative legitimately depends on
+        # the last bits of the GEMM -- same masking as tests/test_gpu_conv.py)
+        gout = torch.randn(yr.shape, generator=g, dtype=torch.float64) * (z.detach().abs() > 1e-3).double()
+        yr.backward(gout)
+        conv = conv.to(d)
+        xg = x.to(d).requires_grad_(True)
+        y = RF.conv2d(xg, conv, act=RF.ACT_LRELU, slope=0.1)
+        y.backward(gout.float().to(d))
+        errs = [rel_err(y.detach().cpu(), yr.detach()), rel_err(xg.grad.cpu(), xr.grad), rel_err(conv.weight.grad.cpu(), wr.grad)]
+        print('conv', k, s, Ci, Co, ' '.join('%.1e' % e for e in errs))
+        worst = max(worst, max(errs))
+    torch.cuda.synchronize()
+    print('worst rel_err %.3e' % worst)
+    return 0 if worst <= 1e-4 else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())

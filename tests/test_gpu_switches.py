@@ -1,0 +1,24 @@
+"""Every developer switch that selects an older kernel generation or a fixed variant (realvsr_amd/csrc: RVSR_DCN_FWD, RVSR_DCN_BWD, RVSR_DCN_BWDW, RVSR_DCN5_HALO, RVSR_DCN_MT_WIDE, RVSR_XCD_SWIZZLE) still produces reference
+arithmetic: those kernels are also the fallbacks for geometries the newest ones do not cover.  The switches are read once per
+process, so each setting runs tests/switch_check.py in a subprocess.  -m gpu"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SETTINGS = ['RVSR_DCN_FWD=2', 'RVSR_DCN_BWD=2', 'RVSR_DCN_BWD=3', 'RVSR_DCN_BWD=4',
+            'RVSR_DCN_BWD=5', 'RVSR_DCN5_HALO=2', 'RVSR_DCN5_HALO=5', 'RVSR_DCN5_HALO=8', 'RVSR_DCN5_HALO=12', 'RVSR_DCN_BWDW=3',
+            'RVSR_DCN_BWDW=2', 'RVSR_DCN_MT_WIDE=2', 'RVSR_XCD_SWIZZLE=0', 'RVSR_FLAT_GRAD_ADOPT=0']
+
+
+@pytest.mark.parametrize('setting', SETTINGS)
+def test_switch_keeps_parity(setting):
+    k, v = setting.split('=')
+    env = dict(os.environ, **{k: v})
+    out = subprocess.run([sys.executable, os.path.join(HERE, 'switch_check.py')], env=env, capture_output=True, text=True, timeout=600)
+    print(out.stdout[-400:])
+    assert out.returncode == 0, (setting, out.stdout[-800:], out.stderr[-1500:])

@@ -264,6 +264,58 @@ def test_optimize_parameters_vs_reference_model(gemm_mode, tag):
     check_l2('post-step fake_H[:, 0]', fake_y, ref_y, 2e-4 if gemm_mode == 'f32' else 2e-3)
 
 
+def test_combine_model_vs_reference_model(gemm_mode):
+    """2 steps of VideoSRModel(split=False).optimize_parameters vs the reference's Combine model class
+    (VideoSR_AllPair_model_YCbCr_Combine.py:187-221; fixture train_step_combine.npz from make_golden.main_train_step_combine):
+    l_tot = 1.0 * Charbonnier on all three channels + 0.5 * PyramidLoss(3, 'lap', 'cb') as the edge term.  Every op pinned."""
+    from weights import fill_state_dict
+    from oracle import edvr_oracle as O
+    from realvsr_amd.VideoSR_model import create_model
+    g = load_golden('train_step_combine')
+    torch.cuda.set_device(0)
+    opt = _train_opt('cb')
+    opt['model'] = 'VideoSR_AllPair_YCbCr_Combine'
+    opt['train'] = {'pixel_criterion': 'cb', 'pixel_weight': 1.0, 'edge_criterion': 'pyr', 'edge_weight': 0.5,
+                    'feature_criterion': None, 'feature_weight': 0, 'weight_decay_G': 0, 'ft_tsa_only': 0, 'lr_G': 1e-3,
+                    'beta1': 0.9, 'beta2': 0.99}
+    model = create_model(opt)
+    assert model.split is False and model.cri_edg is not None
+    fill_state_dict(model.netG, 909, offset_std=0.02)
+    model.optimizer_G.buffers.check_bound()
+    gt_c = torch.from_numpy(g['GT_center'])
+    GT = torch.zeros(2, 3, 3, 64, 96)
+    GT[:, 1] = gt_c
+    data = {'LQs': torch.from_numpy(g['LQs']), 'GT': GT}
+    ltol = 2e-5 if gemm_mode == 'f32' else 1e-4
+    before = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+    for step in (1, 2):
+        model.feed_data(data)
+        model.optimize_parameters(step)
+        log = model.get_current_log()
+        for name, w in zip(('l_tot', 'l_edg'), g['logs'][step - 1]):
+            assert abs(log[name] - w) <= ltol * abs(w), (step, name, log[name], w)
+        if step == 1:
+            gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.netG.parameters())).item()
+            want_g = float(g['gnorm1'])
+            assert abs(gnorm - want_g) <= (1e-3 if gemm_mode == 'f32' else 5e-3) * want_g, (gnorm, want_g)
+    num = den = 0.0
+    for k, v in model.netG.state_dict().items():
+        d_ref = torch.from_numpy(g['after.' + k]).double() - before[k].cpu().double()
+        d_got = v.detach().cpu().double() - before[k].cpu().double()
+        num += float((d_got - d_ref).pow(2).sum())
+        den += float(d_ref.pow(2).sum())
+    rel = (num / den) ** 0.5
+    print('Combine model, parameter update after 2 steps: rel l2 err %.3e' % rel)
+    assert rel <= (2e-2 if gemm_mode == 'f32' else 6e-2), rel
+    model.feed_data(data)
+    model.test()
+    fake, ref = model.fake_H.cpu(), torch.from_numpy(g['fake_H'])
+    p_build, p_ref = O.psnr_y_uint8(fake[:, 0:1], gt_c[:, 0:1]), O.psnr_y_uint8(ref[:, 0:1], gt_c[:, 0:1])
+    print('post-step PSNR-Y vs GT: build %.6f dB, reference %.6f dB' % (p_build, p_ref))
+    assert abs(p_build - p_ref) <= 1e-3
+    check_l2('post-step fake_H', fake, ref, 2e-4 if gemm_mode == 'f32' else 2e-3)
+
+
 def test_model_step_is_sync_free_and_augments():
     """optimize_parameters(log=False) + the device augmentation path run end to end (ft_tsa_only groups, cutblur/rgb)."""
     from realvsr_amd.VideoSR_model import create_model
