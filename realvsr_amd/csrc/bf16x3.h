@@ -7,11 +7,26 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// hi = bf16(v) (round to nearest even), lo = bf16(v - hi).  The exact residual v - hi comes from v_dot2c_f32_bf16 on the PACKED
+// hi pair -- D = v + <(hi0, hi1), (-1, 0)> -- so the pair is never unpacked to f32 again: 4 v_cvt_pk + 8 v_dot2c + 4 v_cvt_pk = 16
+// vector instructions per 8 values, against 24 for the shift / mask / subtract form hipcc makes of `v - (float)hi`.  hi0 * -1 and
+// the sum are exact (Sterbenz), so the result is bit-identical to that form (tools/micro/split_check.hip: 16.7 M random values) unless
+// the OTHER value of a pair rounds to +-inf in bf16 (|v| > 3.39e38: 0 * inf).  The two selector constants are kept out of the
+// inline-constant encoder on purpose: as literals this hipcc emits `1.0` for the packed pair (1, 0), which the hardware reads as (0, 1).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    unsigned u0 = 0x0000bf80u, u1 = 0xbf800000u;   // (-1, 0) and (0, -1) as packed bf16
+    asm volatile("" : "+s"(u0), "+s"(u1));
+    const bf16x2 m0 = __builtin_bit_cast(bf16x2, u0), m1 = __builtin_bit_cast(bf16x2, u1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    for (int j = 0; j < 8; j += 2) {
+        const bf16x2 h = {(__bf16)v[j], (__bf16)v[j + 1]};
+        const float l0 = __builtin_amdgcn_fdot2_f32_bf16(h, m0, v[j], false);
+        const float l1 = __builtin_amdgcn_fdot2_f32_bf16(h, m1, v[j + 1], false);
+        hi[j] = h[0];
+        hi[j + 1] = h[1];
+        lo[j] = (__bf16)l0;
+        lo[j + 1] = (__bf16)l1;
     }
 }
 

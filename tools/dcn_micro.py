@@ -18,12 +18,15 @@ ap.add_argument('--H', type=int, default=180)
 ap.add_argument('--W', type=int, default=320)
 ap.add_argument('--ostd', type=float, default=1.0, help='std of the offsets in pixels')
 ap.add_argument('--fwd-only', action='store_true')
+ap.add_argument('--coherent', type=float, default=None, help='all offsets equal to this value (no sub-pixel sign jitter between neighbouring pixels)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.C, a.H, a.W, generator=g).to(dev).requires_grad_(True)
 om = torch.randn(a.B, 216, a.H, a.W, generator=g)
 om[:, :144] *= a.ostd
+if a.coherent is not None:
+    om[:, :144] = a.coherent
 om = om.to(dev).requires_grad_(True)
 w = (torch.randn(a.C, a.C, 3, 3, generator=g) / 24).to(dev).requires_grad_(True)
 b = torch.zeros(a.C, device=dev, requires_grad=True)
