@@ -225,6 +225,8 @@ class _Snapshot:
         o._steps = list(self.steps)
         for t, v in zip(o._step_t, self.steps):
             t.fill_(float(v))
+        from realvsr_amd import functional as RF
+        RF.packed_weights.repack()   # the flat parameter buffer was overwritten behind torch's version counters
 
 
 def timed_steps(model, n, first_step):

@@ -86,7 +86,10 @@ int rvsr_modulated_deform_conv_backward(const float* input, const float* weight,
 /* Fused core of ModulatedDeformConvPack.forward (deform_conv.py:274-292): `om` is the raw
  * (B,3*dg*9,Ho,Wo) output of conv_offset_mask; torch.chunk/torch.cat become addressing (channels
  * [0,2*dg*9) are the offsets, the rest mask logits) and torch.sigmoid runs in-kernel.
- * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) applied to the output (EDVR_arch.py:107,130). */
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) applied to the output (EDVR_arch.py:107,130); act | 0x100: `workspace`
+ * already holds this layer's packed weight image (rvsr_dcn_pack_weights / rvsr_pack_weights_batched), skip the per-call pack. */
+size_t rvsr_dcn_pack_weights(const float* weight, int channels, int channels_out, void* out, size_t out_bytes,
+                             long long* desc, void* stream);
 int rvsr_dcn_pack_forward(const float* input, const float* weight, const float* bias, const float* om,
                           float* output, int batch, int channels, int height, int width, int channels_out,
                           int stride, int pad, int dilation, int deformable_group, int act, float slope,
@@ -115,7 +118,8 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
  *   xact (NULL or a tensor stored like x1): value *= (xact > 0 ? 1 : xact_slope), i.e. the
  *              ReLU / LeakyReLU derivative taken from the saved activation output.
  *   weight: w_mode 0 -> (Co, C1+C2, k, k) used as is;
- *           w_mode 1 -> (C1+C2, Co, k, k) used transposed + spatially flipped (data gradient).
+ *           w_mode 1 -> (C1+C2, Co, k, k) used transposed + spatially flipped (data gradient);
+ *           w_mode | 2: `workspace` already holds the packed image of these weights (section 2b), the per-call pack is skipped.
  *   out1 (B,Co1,Hout,Wout) [+ out2 (B,Co2,Hout,Wout): rows split, for the gradient of a cat].
  *   residual (NULL or shaped like out1, out2 must be NULL): added after the activation.
  *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
@@ -133,6 +137,19 @@ int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const 
                         const float* residual, float* out1, int Co1, float* out2, int Co2, int B, int ksize,
                         int stride, int w_mode, int act, float slope, int pixel_shuffle, int Hout, int Wout,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* 2b. Packed weight images, once per optimizer step.  The matrix-core kernels stage weights as bf16 hi/lo images
+ *   ([m-block][chunk][hi|lo][tap][octet][row][8]); rvsr_conv2d_forward builds that image in its workspace on every call.
+ *   rvsr_conv2d_pack_weights / rvsr_dcn_pack_weights write the image of one layer (forward: w_mode 0, data gradient: w_mode 1) to
+ *   caller-owned memory of rvsr_conv2d_forward_workspace_bytes(C_in, 0, Co, ksize) /
+ *   rvsr_modulated_deform_conv_forward_workspace_bytes(channels, channels_out) bytes and return that size (0 = bad argument);
+ *   `desc` (NULL or 10 x long long, host) receives {weight, out, Co, C_in, taps, MP, CCG, nchunks, nmb, mode}.
+ *   rvsr_pack_weights_batched re-packs n images in ONE launch from a DEVICE table of 48-byte records
+ *   {const float* w; void* out; int Co, C_in, taps, MP, CCG, nchunks, nmb, mode;} built from those descriptors: the host
+ *   (realvsr_amd.functional.PackedWeights) calls it once after the optimizer has updated the parameters in place. */
+size_t rvsr_conv2d_pack_weights(const float* weight, int C_in, int Co, int ksize, int w_mode, void* out, size_t out_bytes,
+                                long long* desc, void* stream);
+int rvsr_pack_weights_batched(const void* descs, int n, void* stream);
 
 /* grad_weight (Co,C1+C2,k,k) and grad_bias (Co) (NULL = skip) of the conv above.
  *   gout: gradient w.r.t. the conv output.  g_mode 0: stored (B,Co,Gs_h,Gs_w) = (.., Hout, Wout);

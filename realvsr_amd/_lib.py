@@ -27,6 +27,9 @@ SIGNATURES = {
                                     c_fp, c_int, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                     c_int, c_int, c_fp, c_size, c_fp]),
     'rvsr_conv2d_forward_workspace_bytes': (c_size, [c_int] * 4),
+    'rvsr_conv2d_pack_weights': (c_size, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_size, ctypes.POINTER(ctypes.c_longlong), c_fp]),
+    'rvsr_dcn_pack_weights': (c_size, [c_fp, c_int, c_int, c_fp, c_size, ctypes.POINTER(ctypes.c_longlong), c_fp]),
+    'rvsr_pack_weights_batched': (c_int, [c_fp, c_int, c_fp]),
     'rvsr_set_gemm_mode': (None, [c_int]),
     'rvsr_get_gemm_mode': (c_int, []),
     'rvsr_conv2d_wgrad_workspace_bytes': (c_size, [c_int] * 8),

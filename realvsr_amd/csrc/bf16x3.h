@@ -58,12 +58,18 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
 // packed[mb][chunk][part][tap][oc][m][8]: part 0 = hi, 1 = lo; oc < 2*CCG octets of the chunk;
 // m < MP rows of m-block mb.   mode 0: A[o][(tap,c)] = w[o][c][tap]  (w: [Co][Ctot][T])
 //                               mode 1: A[i][(tap,k)] = w[k][i][T-1-tap]  (w: [Ctot][Co][T])
-#ifdef RVSR_DEFINE_PACK
-__global__ void pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int Ctot, int T,
-                                    int MP, int CCG, int nchunks, int nmb, int mode) {
+// One pre-packed weight image: what pack_weights_kernel writes for (w, Co, Ctot, T, MP, CCG, nchunks, nmb, mode).
+// rvsr_pack_weights_batched re-packs a whole table of them in ONE launch (once per optimizer step, realvsr_amd.functional).
+struct PackDesc {
+    const float* w;
+    bf16x8* out;
+    int Co, Ctot, T, MP, CCG, nchunks, nmb, mode;
+};
+__device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int Ctot, int T,
+                                                  int MP, int CCG, int nchunks, int nmb, int mode, size_t first, size_t step) {
     const int noct = 2 * CCG;
     const size_t total = (size_t)nmb * nchunks * T * noct * MP;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = first; idx < total; idx += step) {
         const int m = (int)(idx % MP);
         size_t r = idx / MP;
         const int oc = (int)(r % noct);
@@ -91,7 +97,20 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, bf16x8* __restr
         packed[(blk + 1) * per + inner] = lo;
     }
 }
+#ifdef RVSR_DEFINE_PACK
+__global__ void pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int Ctot, int T,
+                                    int MP, int CCG, int nchunks, int nmb, int mode) {
+    pack_weights_body(w, packed, Co, Ctot, T, MP, CCG, nchunks, nmb, mode, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                      (size_t)gridDim.x * blockDim.x);
+}
+// grid (blocks per image, images)
+__global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    pack_weights_body(d.w, d.out, d.Co, d.Ctot, d.T, d.MP, d.CCG, d.nchunks, d.nmb, d.mode,
+                      (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
 #else
 __global__ void pack_weights_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int Ctot, int T,
                                     int MP, int CCG, int nchunks, int nmb, int mode);
+__global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs);
 #endif

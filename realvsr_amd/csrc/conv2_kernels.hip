@@ -875,8 +875,9 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
     }
     const int T = ksize * ksize;
     const size_t total = (size_t)nmb * nchunks * T * (2 * ccg) * (mt * 32);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, p.Co,
-                       Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode);
+    if (!p.prepacked)
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, p.Co,
+                           Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode);
     p.wpack = workspace;
     p.swz = rvsr_swizzle_enabled();
     p.vec4 = (p.Wout % 4 == 0) && ((((uintptr_t)p.out1) | ((uintptr_t)p.res)) & 15) == 0 && !p.ps && p.out2 == nullptr;
@@ -890,6 +891,36 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
     if (ksize == 3 && stride == 2) DISPATCH2(3, 2, 1);
     DISPATCH2(1, 1, 2);
 #undef DISPATCH2
+}
+
+// Pre-packed weight images (include/realvsr_hip.h section 2b): the image rvsr_conv2d_forward would build in its workspace,
+// written to caller-owned memory so that it can be reused until the weights change; `desc` (10 x int64, host) describes the image
+// for rvsr_pack_weights_batched.
+extern "C" size_t rvsr_conv2d_pack_weights(const float* weight, int C_in, int Co, int ksize, int w_mode, void* out, size_t out_bytes,
+                                           long long* desc, void* stream) {
+    int mt, ccg, nchunks, nmb;
+    fwd2_geom(ksize, Co, C_in, mt, ccg, nchunks, nmb);
+    const size_t need = rvsr_conv_fwd2_workspace_bytes(ksize, Co, C_in);
+    if (!weight || !out || out_bytes < need) return 0;
+    const int T = ksize * ksize;
+    const size_t total = (size_t)nmb * nchunks * T * (2 * ccg) * (mt * 32);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, (bf16x8*)out, Co,
+                       C_in, T, mt * 32, ccg, nchunks, nmb, w_mode & 1);
+    if (desc) {
+        desc[0] = (long long)(uintptr_t)weight; desc[1] = (long long)(uintptr_t)out;
+        desc[2] = Co; desc[3] = C_in; desc[4] = T; desc[5] = mt * 32; desc[6] = ccg; desc[7] = nchunks; desc[8] = nmb; desc[9] = w_mode & 1;
+    }
+    return need;
+}
+// descs: device array of n PackDesc records (built from the 10 x int64 descriptors: two pointers + eight 32-bit fields)
+extern "C" int rvsr_pack_weights_batched(const void* descs, int n, void* stream) {
+    if (n <= 0) return RVSR_OK;
+    if (!descs) FAIL(RVSR_ERR_BAD_ARG, "pack_weights_batched: null table");
+    static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the C ABI (two pointers + eight ints)");
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(16, (unsigned)n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "pack_weights_batched launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
 }
 
 // ==========================================================================================

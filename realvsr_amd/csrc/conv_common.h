@@ -16,6 +16,7 @@ struct ConvFwdParams {
     int Co1;
     int B, Co, Hout, Wout;
     int w_mode;
+    int prepacked;      // `workspace` already holds the packed weight image of this call (rvsr_conv2d_pack_weights / _batched)
     int act;
     float slope;
     int ps;

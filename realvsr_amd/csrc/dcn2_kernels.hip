@@ -219,6 +219,22 @@ static int launch_dcn_fwd2(const DcnFwdParams& p, const bf16x8* wpack, hipStream
     return RVSR_OK;
 }
 
+// the forward's weight image in caller-owned memory (+ its descriptor for rvsr_pack_weights_batched), see include/realvsr_hip.h
+extern "C" size_t rvsr_dcn_pack_weights(const float* weight, int C, int Co, void* out, size_t out_bytes, long long* desc, void* stream) {
+    int mt, nchunks, nmb;
+    fwd2_geom(Co, C, mt, nchunks, nmb);
+    const size_t need = rvsr_dcn_fwd2_workspace_bytes(Co, C);
+    if (!weight || !out || out_bytes < need) return 0;
+    const size_t total = (size_t)nmb * nchunks * 9 * 2 * (mt * 32);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, (bf16x8*)out, Co,
+                       C, 9, mt * 32, 1, nchunks, nmb, 0);
+    if (desc) {
+        desc[0] = (long long)(uintptr_t)weight; desc[1] = (long long)(uintptr_t)out;
+        desc[2] = Co; desc[3] = C; desc[4] = 9; desc[5] = mt * 32; desc[6] = 1; desc[7] = nchunks; desc[8] = nmb; desc[9] = 0;
+    }
+    return need;
+}
+
 int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const DcnGeom& d = p.d;
     if (d.cpg % 8 != 0) return RVSR_ERR_UNSUPPORTED;  // a k-octet must lie inside one deformable group
@@ -227,8 +243,9 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
     const size_t need = rvsr_dcn_fwd2_workspace_bytes(d.Co, d.C);
     if (!workspace || workspace_bytes < need) FAIL(RVSR_ERR_WORKSPACE, "dcn forward: workspace %zu B < %zu B", workspace_bytes, need);
     const size_t total = (size_t)nmb * nchunks * 9 * 2 * (mt * 32);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, d.Co,
-                       d.C, 9, mt * 32, 1, nchunks, nmb, 0);
+    if (!p.prepacked)
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, d.Co,
+                           d.C, 9, mt * 32, 1, nchunks, nmb, 0);
     const bf16x8* wp = (const bf16x8*)workspace;
     static const int gen = [] { const char* e = getenv("RVSR_DCN_FWD"); return e ? atoi(e) : 3; }();  // developer A/B switch
     if (gen >= 3) {

@@ -76,6 +76,7 @@ struct DcnFwdParams {
     float* out;         // (B, Co, Ho, Wo)
     int act;
     float slope;
+    int prepacked;      // the workspace already holds the packed weight image (rvsr_dcn_pack_weights / rvsr_pack_weights_batched)
 };
 
 

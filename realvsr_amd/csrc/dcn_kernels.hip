@@ -378,9 +378,9 @@ static int fill_geom(DcnGeom& d, const float* x, const float* offset, size_t off
 }
 
 static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, float* out, int act, float slope,
-                            void* workspace, size_t workspace_bytes, hipStream_t st) {
+                            void* workspace, size_t workspace_bytes, hipStream_t st, int prepacked = 0) {
     DcnFwdParams p;
-    p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act; p.slope = slope;
+    p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act & 0xff; p.slope = slope; p.prepacked = prepacked;
     if (rvsr_g_gemm_mode == 0 && workspace != nullptr) {  // bf16x3 second-generation kernel
         const int rc = rvsr_launch_dcn_fwd2(p, workspace, workspace_bytes, st);
         if (rc != RVSR_ERR_UNSUPPORTED) return rc;
@@ -560,7 +560,8 @@ extern "C" int rvsr_dcn_pack_forward(const float* input, const float* weight, co
     const size_t hw = (size_t)d.Ho * d.Wo;
     d.off_bs = d.mask_bs = (size_t)27 * deformable_group * hw;
     d.mask = om + (size_t)18 * deformable_group * hw;
-    return dcn_forward_impl(d, weight, bias, output, act, slope, workspace, workspace_bytes, (hipStream_t)stream);
+    // act bit 8: `workspace` already holds the packed weight image (rvsr_dcn_pack_weights), skip the per-call pack
+    return dcn_forward_impl(d, weight, bias, output, act, slope, workspace, workspace_bytes, (hipStream_t)stream, (act >> 8) & 1);
 }
 
 extern "C" int rvsr_dcn_pack_backward(const float* input, const float* weight, const float* om, const float* grad_output,

@@ -32,6 +32,8 @@ def broadcast_parameters(module_or_tensors, src=0, process_group=None):
         tensors = [t.data if isinstance(t, torch.nn.Parameter) else t for t in module_or_tensors]
     for t in tensors:
         dist.broadcast(t, src=src, group=process_group)
+    from . import functional as RF
+    RF.packed_weights.invalidate()   # parameters were overwritten through .data (no version bump)
 
 
 class BucketedGradAllReduce:
@@ -44,6 +46,8 @@ class BucketedGradAllReduce:
         self.flat = self.buffers.grad
         if broadcast and self.world > 1:
             dist.broadcast(self.buffers.param, src=0, group=process_group)   # one collective for all parameters
+            from . import functional as RF
+            RF.packed_weights.invalidate()
         self.buckets = []       # (start, end) ranges in self.flat, ascending
         self._bucket_of = {}
         cap = int(bucket_mb * (1 << 20) / 4)

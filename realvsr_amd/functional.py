@@ -119,6 +119,154 @@ def _pgrad(p, zero=False):
     return torch.zeros_like(p) if zero else torch.empty_like(p)
 
 
+
+# ------------------------------------------------------------------------------------------ packed weights, once per step
+class PackedWeights:
+    """bf16 hi/lo weight images (what the conv / DCN kernels stage into LDS), packed ONCE per optimizer step.
+
+    A conv block needs its weights re-packed ([m-block][chunk][hi|lo][tap][octet][row][8] bf16) -- once for the forward and once,
+    transposed and flipped, for the data gradient.  The library does that per call into the workspace (~150 launches of a 5 us
+    kernel per training step).  Here the images of parameters that live in optim.FlatBuffers are kept in their own tensors,
+    the first use of an image packs it with one call (rvsr_conv2d_pack_weights / rvsr_dcn_pack_weights), and from then on
+    ``FlatAdam.step`` re-packs ALL registered images with ONE launch (rvsr_pack_weights_batched) right after the update.
+    Validity: an entry is used only while (a) the very same parameter object is alive, (b) its torch version counter is
+    unchanged (load_state_dict, in-place edits under no_grad bump it) and (c) it was packed in the current epoch; everything
+    that writes parameters behind torch's back (the flat Adam kernel, a broadcast into the flat buffer, a raw copy into it) must
+    call ``repack()`` (re-pack now) or ``invalidate()`` (forget).  Foreign weights (not in FlatBuffers) take the per-call path.
+    RVSR_PACK_CACHE=0 turns the cache off."""
+
+    def __init__(self):
+        self.entries = {}          # key -> [packed tensor, weakref(weight), version, epoch, desc (10 ints), weight.data_ptr()]
+        self.slices = {}           # (id(weight), C1) -> [w_a, w_b, weakref(weight), version, epoch, data_ptr]
+        self.epoch = 0
+        self.table = None          # device copy of the descriptor table, rebuilt when entries were added or dropped
+        self.enabled = os.environ.get('RVSR_PACK_CACHE', '1') != '0'
+        self.stats = {'hits': 0, 'packs': 0, 'batched': 0}
+
+    def invalidate(self):
+        self.entries.clear()
+        self.slices.clear()
+        self.table = None
+        self.epoch += 1
+
+    @staticmethod
+    def _version(t):
+        """Version of the parameter a weight tensor stands for: its own, or its parent's for a cached input-channel slice."""
+        parent = getattr(t, '_rvsr_parent', None)
+        if parent is None:
+            return t._version
+        parent = parent()
+        return -1 if parent is None else parent._version
+
+    def split(self, weight, C1):
+        """weight[:, :C1] and weight[:, C1:] as PERSISTENT contiguous tensors (conv_cat_bcast convolves the two halves of a concat
+        conv separately): copied on first sight and after every optimizer step (repack), so that their packed images can be
+        cached like those of whole parameters.  Falls back to fresh copies for weights outside FlatBuffers."""
+        if not self.enabled or getattr(weight, '_rvsr_grad_home', None) is None:
+            return weight[:, :C1].contiguous(), weight[:, C1:].contiguous()
+        import weakref
+        key = (id(weight), C1)
+        e = self.slices.get(key)
+        if e is not None and e[2]() is weight and e[3] == weight._version and e[4] == self.epoch and e[5] == weight.data_ptr():
+            return e[0], e[1]
+        if e is not None and e[2]() is weight and e[0].device == weight.device:
+            w_a, w_b = e[0], e[1]
+            with torch.no_grad():
+                w_a.copy_(weight[:, :C1])
+                w_b.copy_(weight[:, C1:])
+        else:
+            w_a, w_b = weight[:, :C1].detach().contiguous(), weight[:, C1:].detach().contiguous()
+            w_a._rvsr_parent = w_b._rvsr_parent = weakref.ref(weight)
+        self.slices[key] = [w_a, w_b, weakref.ref(weight), weight._version, self.epoch, weight.data_ptr()]
+        return w_a, w_b
+
+    def get(self, weight, kind, C_in, Co, k, w_mode, nbytes):
+        """Packed image tensor for (weight, kind, geometry), or None when the weight is not cacheable."""
+        if not self.enabled or _lib.get_gemm_mode() != 'bf16x3':
+            return None
+        if getattr(weight, '_rvsr_grad_home', None) is None and getattr(weight, '_rvsr_parent', None) is None:
+            return None
+        key = (id(weight), kind, C_in, Co, k, w_mode)
+        e = self.entries.get(key)
+        if e is not None and e[1]() is weight and e[2] == self._version(weight) and e[3] == self.epoch and e[5] == weight.data_ptr():
+            self.stats['hits'] += 1
+            return e[0]
+        import weakref
+        L = _lib.lib()
+        buf = e[0] if e is not None and e[0].numel() >= nbytes and e[0].device == weight.device else \
+            torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device)
+        desc = (ctypes.c_longlong * 10)()
+        if kind == 'conv':
+            got = L.rvsr_conv2d_pack_weights(_p(weight), C_in, Co, k, w_mode, _p(buf), buf.numel(), desc, _stream())
+        else:
+            got = L.rvsr_dcn_pack_weights(_p(weight), C_in, Co, _p(buf), buf.numel(), desc, _stream())
+        if got == 0:
+            return None
+        self.stats['packs'] += 1
+        self.entries[key] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc), weight.data_ptr()]
+        self.table = None
+        return buf
+
+    def repack(self):
+        """Re-pack every live image in one launch (the parameters were just updated in place) and start a new epoch."""
+        self.epoch += 1
+        if not self.enabled or not self.entries:
+            return
+        for k, e in list(self.slices.items()):     # refresh the persistent input-channel slices first: their images are packed below
+            parent = e[2]()
+            if parent is None or e[3] != parent._version or e[5] != parent.data_ptr():
+                del self.slices[k]
+                continue
+            with torch.no_grad():
+                e[0].copy_(parent[:, :k[1]])
+                e[1].copy_(parent[:, k[1]:])
+            e[4] = self.epoch
+        dead = [k for k, e in self.entries.items() if e[1]() is None or e[2] != self._version(e[1]()) or e[5] != e[1]().data_ptr()]
+        for k in dead:
+            del self.entries[k]
+            self.table = None
+        if not self.entries:
+            return
+        by_dev = {}
+        for e in self.entries.values():
+            by_dev.setdefault(e[0].device, []).append(e)
+        if self.table is None:
+            self.table = {}
+            for dev, es in by_dev.items():
+                # PackDesc = two pointers + eight 32-bit fields (48 bytes)
+                raw = torch.empty(len(es), 6, dtype=torch.int64)
+                for i, e in enumerate(es):
+                    d = e[4]
+                    raw[i, 0], raw[i, 1] = d[0], d[1]
+                    for j in range(4):
+                        raw[i, 2 + j] = (d[2 + 2 * j] & 0xffffffff) | ((d[3 + 2 * j] & 0xffffffff) << 32)
+                self.table[dev] = (raw.to(dev), len(es))
+        for dev, es in by_dev.items():
+            tab, n = self.table[dev]
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().rvsr_pack_weights_batched(_p(tab), n, _stream()), 'pack_weights_batched')
+            for e in es:
+                e[3] = self.epoch
+        self.stats['batched'] += 1
+
+
+packed_weights = PackedWeights()
+
+
+def _conv_fwd(L, x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias, residual, out1, Co1, out2, Co2, B, k, stride, w_mode,
+              act, slope, ps, Hout, Wout, what, wparam=None):
+    """rvsr_conv2d_forward with the weight image from the per-step cache when `wparam` (the nn.Parameter behind `weight`,
+    default: none = per-call packing into the shared scratch) lives in FlatBuffers."""
+    nbytes = L.rvsr_conv2d_forward_workspace_bytes(C1, C2, Co1 + Co2, k)
+    buf = packed_weights.get(wparam, 'conv', C1 + C2, Co1 + Co2, k, w_mode, nbytes) if wparam is not None else None
+    if buf is not None:
+        ws, w_mode = buf, w_mode | 2
+    else:
+        ws = _workspace(nbytes, torch.device('cuda', torch.cuda.current_device()))
+    _lib.check(L.rvsr_conv2d_forward(x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias, residual, out1, Co1, out2, Co2, B, k,
+                                     stride, w_mode, act, slope, ps, Hout, Wout, _p(ws), ws.numel(), _stream()), what)
+
+
 # ------------------------------------------------------------------------------------------ conv
 class _Conv2dFused(Function):
     """act(conv2d(cat(x1, x2), w) + b) [+ residual] [-> PixelShuffle(2)]"""
@@ -144,10 +292,8 @@ class _Conv2dFused(Function):
         else:
             out = x1.new_empty(B, Co, Ho, Wo)
         L = _lib.lib()
-        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C1, C2, Co, k), x1.device)
-        _lib.check(L.rvsr_conv2d_forward(_p(x1), C1, _p(x2), C2, None, 0.0, 0, H, W, _p(weight), _p(bias),
-                                         _p(residual), _p(out), Co, None, 0, B, k, stride, 0, act, slope,
-                                         int(pixel_shuffle), Ho, Wo, _p(ws), ws.numel(), _stream()), 'conv2d_forward')
+        _conv_fwd(L, _p(x1), C1, _p(x2), C2, None, 0.0, 0, H, W, _p(weight), _p(bias), _p(residual), _p(out), Co, None, 0, B,
+                  k, stride, 0, act, slope, int(pixel_shuffle), Ho, Wo, 'conv2d_forward', wparam=weight)
         ctx.cfg = (stride, act, slope, bool(pixel_shuffle), C1, C2, H, W, Ho, Wo, k, bias is not None,
                    residual is not None)
         ctx.save_for_backward(x1, x2, weight, out if act != ACT_NONE else None)
@@ -177,11 +323,9 @@ class _Conv2dFused(Function):
             gx1 = dep if dep is not None else torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
             in_mode = 2 if ps else (1 if stride == 2 else 0)
-            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1 + C2, k), x1.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2],
-                                             gout.shape[3], _p(weight), None, _p(dep), _p(gx1), C1, _p(gx2), C2, B, k,
-                                             1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                       'conv2d_backward_data')
+            _conv_fwd(L, _p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2], gout.shape[3], _p(weight), None,
+                      _p(dep), _p(gx1), C1, _p(gx2), C2, B, k, 1, 1, ACT_NONE, 0.0, 0, H, W, 'conv2d_backward_data',
+                      wparam=weight)
             if deposit:   # the first depositor's output IS the sink's buffer (no zero fill); autograd gets no gradient from here
                 ctx.dep_sink.buf = gx1
                 gx1 = None
@@ -214,13 +358,10 @@ class _ResBlockFused(Function):
             raise RuntimeError('res_block: expected two %dx%dx3x3 convs' % (C, C))
         L = _lib.lib()
         h, out = torch.empty_like(x), torch.empty_like(x)
-        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), x.device)
-        _lib.check(L.rvsr_conv2d_forward(_p(x), C, None, 0, None, 0.0, 0, H, W, _p(w1), _p(b1), None, _p(h), C, None,
-                                         0, B, 3, 1, 0, ACT_RELU, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                   'res_block conv1')
-        _lib.check(L.rvsr_conv2d_forward(_p(h), C, None, 0, None, 0.0, 0, H, W, _p(w2), _p(b2), _p(x), _p(out), C,
-                                         None, 0, B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                   'res_block conv2')
+        _conv_fwd(L, _p(x), C, None, 0, None, 0.0, 0, H, W, _p(w1), _p(b1), None, _p(h), C, None, 0, B, 3, 1, 0, ACT_RELU,
+                  0.0, 0, H, W, 'res_block conv1', wparam=w1)
+        _conv_fwd(L, _p(h), C, None, 0, None, 0.0, 0, H, W, _p(w2), _p(b2), _p(x), _p(out), C, None, 0, B, 3, 1, 0, ACT_NONE,
+                  0.0, 0, H, W, 'res_block conv2', wparam=w2)
         ctx.save_for_backward(x, h, w1, w2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.bias_p = (b1, b2)   # only to find their gradient buffers (_pgrad)
@@ -246,10 +387,8 @@ class _ResBlockFused(Function):
         if need_x or need_w1 or need_b1:
             # gradient w.r.t. relu(conv1(x)); relu' is applied from h when it is consumed below
             gh = torch.empty_like(x)
-            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), x.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gout), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, None, _p(gh), C,
-                                             None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(),
-                                             _stream()), 'res_block dgrad2')
+            _conv_fwd(L, _p(gout), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, None, _p(gh), C, None, 0, B, 3, 1, 1,
+                      ACT_NONE, 0.0, 0, H, W, 'res_block dgrad2', wparam=w2)
             if need_w1 or need_b1:
                 gw1 = _pgrad(w1)
                 gb1 = _pgrad(ctx.bias_p[0]) if ctx.has_bias[0] else None
@@ -259,10 +398,8 @@ class _ResBlockFused(Function):
                                                          _stream()), 'res_block wgrad1')
             if need_x:
                 gx = torch.empty_like(x)
-                ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), x.device)
-                _lib.check(L.rvsr_conv2d_forward(_p(gh), C, None, 0, _p(h), 0.0, 0, H, W, _p(w1), None, _p(gout),
-                                                 _p(gx), C, None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws),
-                                                 ws.numel(), _stream()), 'res_block dgrad1')
+                _conv_fwd(L, _p(gh), C, None, 0, _p(h), 0.0, 0, H, W, _p(w1), None, _p(gout), _p(gx), C, None, 0, B, 3, 1, 1,
+                          ACT_NONE, 0.0, 0, H, W, 'res_block dgrad1', wparam=w1)
         return gx, gw1, gb1, gw2, gb2
 
 
@@ -290,24 +427,25 @@ class _ConvCatBcast(Function):
         Co, Cw, k, _ = weight.shape
         if NB != N * B or Cw != C1 + C2 or k != 3 or tuple(ref.shape[2:]) != (H, W):
             raise RuntimeError('conv_cat_bcast: x %s, ref %s, weight %s, N %d do not fit' % (tuple(x.shape), tuple(ref.shape), tuple(weight.shape), N))
-        w_a, w_b = weight[:, :C1].contiguous(), weight[:, C1:].contiguous()
+        w_a, w_b = packed_weights.split(weight, C1)   # persistent per-step copies when the weight lives in FlatBuffers
         out = x.new_empty(NB, Co, H, W)
         part = x.new_empty(B, Co, H, W)
         L = _lib.lib()
-        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(max(C1, C2), 0, Co, 3), x.device)
-        _lib.check(L.rvsr_conv2d_forward(_p(x), C1, None, 0, None, 0.0, 0, H, W, _p(w_a), _p(bias), None, _p(out), Co, None,
-                                         0, NB, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast conv_a')
-        _lib.check(L.rvsr_conv2d_forward(_p(ref), C2, None, 0, None, 0.0, 0, H, W, _p(w_b), None, None, _p(part), Co, None,
-                                         0, B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast conv_b')
+        _conv_fwd(L, _p(x), C1, None, 0, None, 0.0, 0, H, W, _p(w_a), _p(bias), None, _p(out), Co, None, 0, NB, 3, 1, 0,
+                  ACT_NONE, 0.0, 0, H, W, 'conv_cat_bcast conv_a', wparam=w_a)
+        _conv_fwd(L, _p(ref), C2, None, 0, None, 0.0, 0, H, W, _p(w_b), None, None, _p(part), Co, None, 0, B, 3, 1, 0,
+                  ACT_NONE, 0.0, 0, H, W, 'conv_cat_bcast conv_b', wparam=w_b)
         _lib.check(L.rvsr_bcast_add_act(_p(out), _p(part), part.numel(), N, act, slope, _stream()), 'bcast_add_act')
         ctx.cfg = (N, act, slope, bias is not None)
-        ctx.save_for_backward(x, ref, w_a, w_b, out if act != ACT_NONE else None)
+        ctx.w_ab = (w_a, w_b)   # (python references: the cached slices carry the attribute the weight-image cache keys on)
+        ctx.save_for_backward(x, ref, out if act != ACT_NONE else None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        x, ref, w_a, w_b, act_out = ctx.saved_tensors
+        x, ref, act_out = ctx.saved_tensors
+        w_a, w_b = ctx.w_ab
         N, act, slope, has_bias = ctx.cfg
         gout = gout.contiguous()
         NB, C1, H, W = x.shape
@@ -329,10 +467,8 @@ class _ConvCatBcast(Function):
                     full = ref_sink.buf = ref.new_zeros(ref_sink.shape)
                 blk = full[ref_block * B:(ref_block + 1) * B]
             gref = blk if blk is not None else torch.empty_like(ref)
-            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C2, 3), x.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gpart), Co, None, 0, None, 0.0, 0, H, W, _p(w_b), None, _p(blk), _p(gref), C2,
-                                             None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                       'conv_cat_bcast dgrad_b')
+            _conv_fwd(L, _p(gpart), Co, None, 0, None, 0.0, 0, H, W, _p(w_b), None, _p(blk), _p(gref), C2, None, 0, B, 3, 1,
+                      1, ACT_NONE, 0.0, 0, H, W, 'conv_cat_bcast dgrad_b', wparam=w_b)
             if blk is not None:
                 gref = None  # deposited into the block of the full tensor's sink
         if ctx.needs_input_grad[0]:
@@ -341,10 +477,8 @@ class _ConvCatBcast(Function):
                 dep = x_sink.close() if x_owner else x_sink.get(x)
             gx = dep if dep is not None else torch.empty_like(x)
             # a fresh sink buffer is all zeros: adding it as the residual is exact and keeps one code path
-            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(Co, 0, C1, 3), x.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gout), Co, None, 0, _p(act_out), gslope, 0, H, W, _p(w_a), None, _p(dep), _p(gx), C1,
-                                             None, 0, NB, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                       'conv_cat_bcast dgrad_a')
+            _conv_fwd(L, _p(gout), Co, None, 0, _p(act_out), gslope, 0, H, W, _p(w_a), None, _p(dep), _p(gx), C1, None, 0,
+                      NB, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, 'conv_cat_bcast dgrad_a', wparam=w_a)
             if dep is not None and not x_owner:
                 gx = None    # deposited: the owner returns the buffer
         if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
@@ -463,9 +597,13 @@ class _DcnPackFused(Function):
             raise RuntimeError('conv_offset_mask output has shape %s, expected %s' % (tuple(om.shape), (B, 27 * dg, Ho, Wo)))
         out = x.new_empty(B, Co, Ho, Wo)
         L = _lib.lib()
-        ws = _workspace(L.rvsr_modulated_deform_conv_forward_workspace_bytes(C, Co), x.device)
+        nbytes = L.rvsr_modulated_deform_conv_forward_workspace_bytes(C, Co)
+        ws = packed_weights.get(weight, 'dcn', C, Co, 3, 0, nbytes)          # per-step weight image (act bit 8: already packed)
+        flags = 0x100 if ws is not None else 0
+        if ws is None:
+            ws = _workspace(nbytes, x.device)
         _lib.check(L.rvsr_dcn_pack_forward(_p(x), _p(weight), _p(bias), _p(om), _p(out), B, C, H, W, Co, stride,
-                                           padding, dilation, dg, act, slope, _p(ws), ws.numel(), _stream()),
+                                           padding, dilation, dg, act | flags, slope, _p(ws), ws.numel(), _stream()),
                    'dcn_pack_forward')
         ctx.cfg = (stride, padding, dilation, dg, act, slope, bias is not None)
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
@@ -608,12 +746,11 @@ class _TSATemporalBlock(Function):
         L = _lib.lib()
         emb = aligned.new_empty(N, B, C, H, W)
         emb_ref = aligned.new_empty(B, C, H, W)
-        ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), aligned.device)
         cen = aligned[center]
-        _lib.check(L.rvsr_conv2d_forward(_p(aligned), C, None, 0, None, 0.0, 0, H, W, _p(w1), _p(b1), None, _p(emb), C, None, 0,
-                                         N * B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'tsa tAtt_1')
-        _lib.check(L.rvsr_conv2d_forward(_p(cen), C, None, 0, None, 0.0, 0, H, W, _p(w2), _p(b2), None, _p(emb_ref), C, None, 0,
-                                         B, 3, 1, 0, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()), 'tsa tAtt_2')
+        _conv_fwd(L, _p(aligned), C, None, 0, None, 0.0, 0, H, W, _p(w1), _p(b1), None, _p(emb), C, None, 0, N * B, 3, 1, 0,
+                  ACT_NONE, 0.0, 0, H, W, 'tsa tAtt_1', wparam=w1)
+        _conv_fwd(L, _p(cen), C, None, 0, None, 0.0, 0, H, W, _p(w2), _p(b2), None, _p(emb_ref), C, None, 0, B, 3, 1, 0,
+                  ACT_NONE, 0.0, 0, H, W, 'tsa tAtt_2', wparam=w2)
         mod = aligned.new_empty(B, N * C, H, W)
         prob = aligned.new_empty(B, N, H, W)
         _lib.check(L.rvsr_tsa_temporal_forward(_p(emb), _p(emb_ref), _p(aligned), _p(mod), _p(prob), B, N, C, H, W, 1, _stream()),
@@ -652,14 +789,11 @@ class _TSATemporalBlock(Function):
         if ctx.needs_input_grad[0]:
             # galigned += dgrad(tAtt_1)(gemb), in place: the kernel's fused residual is its own output buffer (every lane reads
             # the residual values of exactly the addresses it then stores)
-            ws = _workspace(L.rvsr_conv2d_forward_workspace_bytes(C, 0, C, 3), aligned.device)
-            _lib.check(L.rvsr_conv2d_forward(_p(gemb), C, None, 0, None, 0.0, 0, H, W, _p(w1), None, _p(galigned), _p(galigned), C,
-                                             None, 0, N * B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                       'tsa dgrad tAtt_1')
+            _conv_fwd(L, _p(gemb), C, None, 0, None, 0.0, 0, H, W, _p(w1), None, _p(galigned), _p(galigned), C, None, 0,
+                      N * B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, 'tsa dgrad tAtt_1', wparam=w1)
             gcen = galigned[center]
-            _lib.check(L.rvsr_conv2d_forward(_p(gemb_ref), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, _p(gcen), _p(gcen), C,
-                                             None, 0, B, 3, 1, 1, ACT_NONE, 0.0, 0, H, W, _p(ws), ws.numel(), _stream()),
-                       'tsa dgrad tAtt_2')
+            _conv_fwd(L, _p(gemb_ref), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, _p(gcen), _p(gcen), C, None, 0, B, 3, 1,
+                      1, ACT_NONE, 0.0, 0, H, W, 'tsa dgrad tAtt_2', wparam=w2)
         else:
             galigned = None
         return galigned, None, gw1, gb1, gw2, gb2

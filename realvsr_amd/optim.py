@@ -67,6 +67,7 @@ class FlatBuffers:
                 p.grad = self.grad[o:o + n].view(p.shape)
                 # where the fused operators of realvsr_amd.functional write this parameter's gradient (see zero_grad)
                 p._rvsr_grad_home = (self.grad, o, self.claimed)
+        RF.packed_weights.invalidate()   # (parameters moved: weight images packed from the old storage are stale)
 
     def grad_view(self, p):
         o = self.offset[p]
@@ -175,6 +176,8 @@ class FlatAdam(torch.optim.Optimizer):
             self.buffers.param[s:e].copy_(pv)
             self.exp_avg[s:e].copy_(m1)
             self.exp_avg_sq[s:e].copy_(m2)
+        # the kernels above changed every parameter through raw pointers: re-pack all cached bf16 hi/lo weight images, one launch
+        RF.packed_weights.repack()
         return loss
 
     def load_state_dict(self, state_dict):

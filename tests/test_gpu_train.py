@@ -339,3 +339,54 @@ def test_model_step_is_sync_free_and_augments():
             assert torch.equal(model.netG.conv_first.weight.detach(), first0)
             assert not torch.equal(model.netG.tsa_fusion.tAtt_1.weight.detach(), tsa0)
     assert torch.isfinite(model.loss_terms['l_pix']).item() and model.get_current_log() == {}
+
+
+def test_packed_weight_cache_is_bit_identical_and_batched():
+    """functional.PackedWeights: bf16 hi/lo weight images are packed once per optimizer step (one batched launch
+    after FlatAdam.step) instead of once per conv call.  Three training steps with the cache match three steps without it (first
+    loss bit for bit, parameters within the run-to-run noise of the atomic scatter); edits that bypass the optimizer (in-place under no_grad: version bump; load_state_dict)
+    are picked up; after the first step every conv / DCN forward of a step is a cache hit."""
+    from weights import fill_state_dict
+    from realvsr_amd import functional as RF
+    from realvsr_amd.VideoSR_model import create_model
+    torch.cuda.set_device(0)
+    gen = torch.Generator().manual_seed(3)
+    data = {'LQs': torch.rand(2, 3, 3, 24, 32, generator=gen), 'GT': torch.rand(2, 3, 3, 96, 128, generator=gen)}
+
+    def run(enabled):
+        RF.packed_weights.invalidate()
+        RF.packed_weights.enabled = enabled
+        RF.packed_weights.stats = {'hits': 0, 'packs': 0, 'batched': 0}
+        torch.manual_seed(1)
+        model = create_model(_train_opt('cb'))
+        fill_state_dict(model.netG, 808, offset_std=0.02)
+        losses = []
+        for step in (1, 2, 3):
+            model.feed_data(data)
+            model.optimize_parameters(step)
+            losses.append(model.get_current_log()['l_pix'])
+            if step == 2:   # an edit behind the optimizer's back, through torch (version bump): must be seen by step 3
+                with torch.no_grad():
+                    model.netG.conv_first.weight.mul_(1.01)
+                    model.netG.pcd_align.L1_dcnpack.weight.mul_(0.99)
+        return model.optimizer_G.buffers.param.detach().clone(), losses, dict(RF.packed_weights.stats)
+
+    try:
+        p_on, l_on, st_on = run(True)
+        p_off, l_off, st_off = run(False)
+        p_off2, l_off2, _ = run(False)
+    finally:
+        RF.packed_weights.enabled = True
+        RF.packed_weights.invalidate()
+    # the forward pass has no atomics: the first loss is bit-identical; later steps carry the run-to-run noise of the float atomics
+    # in the DCN grad_input flush (two runs WITHOUT the cache differ by it as well) -- the cache must not add to that noise floor
+    assert l_on[0] == l_off[0] == l_off2[0]
+    noise = (p_off - p_off2).double().norm().item()
+    diff = (p_on - p_off).double().norm().item()
+    print('parameters after 3 steps: cache on vs off %.3e, off vs off %.3e (of %.3e)' % (diff, noise, p_off.double().norm().item()))
+    assert diff <= 4 * noise + 1e-7 * p_off.double().norm().item()
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l_on, l_off))
+    assert st_off == {'hits': 0, 'packs': 0, 'batched': 0}
+    # one batched launch per optimizer step; individual packs only on first sight of an image (step 1) and for the two edited weights
+    assert st_on['batched'] == 3 and st_on['hits'] >= 1.9 * (st_on['packs'] - 4) > 0
+    print('packed-weight cache:', st_on)
