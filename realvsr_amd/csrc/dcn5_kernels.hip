@@ -88,6 +88,63 @@ __global__ __launch_bounds__(576) void dcn_bwd5_wnorm_kernel(const float* __rest
     if (t == 0) wn[chunk] = sqrtf(red[0]);
 }
 
+// packed[chunk][mt (3)][part (hi, lo)][o-octet (2*NK)][row (32)][8 o];  row -> tap = 4*mt + (row >> 3), c = 8*chunk + (row & 7)
+template <int NK>
+__global__ void pack_weights_bwd5_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int C, int nchunks) {
+    const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx & 31);
+        size_t r = idx >> 5;
+        const int ooct = (int)(r % (2 * NK));
+        r /= (2 * NK);
+        const int mt = (int)(r % 3), chunk = (int)(r / 3);
+        const int tap = 4 * mt + (row >> 3), c = 8 * chunk + (row & 7);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = 8 * ooct + j;
+            v[j] = (tap < 9 && c < C && o < Co) ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+        }
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        const size_t blk = ((size_t)chunk * 3 + mt) * 2, per = (size_t)(2 * NK) * 32;
+        packed[blk * per + ooct * 32 + row] = hi;
+        packed[(blk + 1) * per + ooct * 32 + row] = lo;
+    }
+}
+
+// Sampled statistic behind the halo selection: every 16th row of every offset plane; cnt[0 / 1 / 2] = components with
+// |v| > 2.5 / 5.5 / 8.5 px (what the R = 2 / 5 / 8 tiles do not cover on either side).
+__global__ void dcn_offset_probe2_kernel(const float* __restrict__ off, size_t off_bs, int B, int planes, int Ho, int Wo,
+                                         unsigned* __restrict__ cnt) {
+    const int nrow = (Ho + 15) / 16;
+    const size_t total = (size_t)B * planes * nrow * Wo;
+    unsigned a = 0, c = 0, e8 = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        size_t r = i / Wo;
+        const int row = (int)(r % nrow);
+        r /= nrow;
+        const int pl = (int)(r % planes), b = (int)(r / planes);
+        const int y = row * 16 + 8 < Ho ? row * 16 + 8 : Ho - 1;
+        const float v = fabsf(off[(size_t)b * off_bs + ((size_t)pl * Ho + y) * Wo + x]);
+        a += v > 2.5f ? 1u : 0u;
+        c += v > 5.5f ? 1u : 0u;
+        e8 += v > 8.5f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        a += __shfl_xor(a, s);
+        c += __shfl_xor(c, s);
+        e8 += __shfl_xor(e8, s);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(cnt, a);
+        if (c) atomicAdd(cnt + 1, c);
+        if (e8) atomicAdd(cnt + 2, e8);
+    }
+}
+
 __device__ __forceinline__ void lds_add_i32(int* p, int v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32
 }
