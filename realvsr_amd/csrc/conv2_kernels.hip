@@ -122,6 +122,72 @@ __device__ __forceinline__ void conv2_epilogue_v4(f32x16 (&acc)[MT][2], const Co
     }
 }
 
+// Epilogue of the 8 x 64 tile (conv_fwd5_kernel<.., WIDE>): acc[m][0] / acc[m][1] are the left / right 32 pixels of ONE row.  After
+// the quad transpose a lane holds 4 consecutive pixels of channel 8 rg + 4 hi + j in each of the two register sets; one
+// v_permlane32_swap per register then gives the lower lane half both pixel halves of channel 8 rg + j (register set 0) and the
+// upper lane half both halves of channel 8 rg + 4 + j (register set 1), so that a store instruction covers 4 channels x 64 pixels
+// = 4 runs of 256 bytes.  (Inline assembly: this hipcc lowers the builtin's second result to a copy of the first.)
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+}
+template <int MT, int MODE>
+__device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const ConvFwdParams& p, const float* bias_s, int b,
+                                                    int o0, int row, int x0, int lo, int hi) {
+    if (row >= p.Hout) return;   // wave-uniform
+    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+    // After transpose + half swap lane 4 G + j holds channel j, pixel quad G = 8 hi + (lo >> 2) of the row.  The store path wants
+    // CONSECUTIVE lanes on consecutive addresses (store_micro.hip: 4 x 256 B per instruction = 26 B/clk with lanes 16 c .. 16 c + 15
+    // on channel c, 15 B/clk with the channels interleaved lane by lane): one ds_bpermute per register moves the value of lane
+    // 4 G + j to lane 16 j + G (LDS crossbar only, no LDS memory).
+    const int lane = 32 * hi + lo, jn = lane >> 4, Gn = lane & 15;
+    const int src4 = 4 * (4 * Gn + jn);                       // byte index of the source lane
+    const int col4 = x0 + 4 * Gn;
+    const bool col_ok = col4 < p.Wout;                        // Wout % 4 == 0
+    const size_t HW = (size_t)p.Hout * p.Wout, pix = (size_t)row * p.Wout + col4;
+    const int j = lo & 3;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float4 resv[2];
+            if (MODE == 1) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int o = o0 + m * 32 + 8 * rg + 4 * s + jn;
+                    const bool ok = col_ok && o < p.Co;
+                    resv[s] = *reinterpret_cast<const float4*>(p.res + (ok ? ((size_t)b * p.Co + o) * HW + pix : 0));
+                }
+            }
+            float r[2][4];
+            const float bb = bias_s[m * 32 + 8 * rg + 4 * hi + j];   // (before the swap a lane's channel is 8 rg + 4 hi + j in both sets)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                r[n][0] = acc[m][n][4 * rg + 0]; r[n][1] = acc[m][n][4 * rg + 1]; r[n][2] = acc[m][n][4 * rg + 2]; r[n][3] = acc[m][n][4 * rg + 3];
+                quad_transpose4(r[n][0], r[n][1], r[n][2], r[n][3], lo);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = r[n][e] + bb;
+                    r[n][e] = v > 0.f ? v : v * neg;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) half_swap(r[0][e], r[1][e]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    r[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, r[s][e])));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {   // set s: lanes 16 c .. 16 c + 15 = channel 8 rg + 4 s + c, the 64 pixels of the row
+                const int o = o0 + m * 32 + 8 * rg + 4 * s + jn;
+                float4 v = make_float4(r[s][0], r[s][1], r[s][2], r[s][3]);
+                if (MODE == 1) { v.x += resv[s].x; v.y += resv[s].y; v.z += resv[s].z; v.w += resv[s].w; }
+                if (col_ok && o < p.Co) *reinterpret_cast<float4*>(p.out1 + ((size_t)b * p.Co + o) * HW + pix) = v;
+            }
+        }
+    }
+}
+
 template <int KS, int STRIDE, int MT, int CCG, bool ACT_IN, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdParams p) {
     constexpr int T = KS * KS, PAD = KS / 2, TH = 2 * NW, TW = 32, NTHR = NW * 64;
@@ -143,8 +209,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
     // ---- persistent schedule: the work items (tile, m-block, batch) are split into 8 contiguous ranges, one per
     // XCD (workgroup w is observed on XCD w % 8: neighbouring tiles then share an L2); inside a range the XCD's
     // workgroups take items round-robin.
-    const unsigned nmb = (p.Co + MP - 1) / MP, nty = (p.Hout + TH - 1) / TH;
-    const unsigned items = p.ntx * nty * nmb * p.B;
+    const unsigned nmb = (p.Co + MP - 1) / MP, nty = (p.Hout + TH - 1) / TH, ntx = (p.Wout + TW - 1) / TW;
+    const unsigned items = ntx * nty * nmb * p.B;
     const unsigned xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, nwq = (gridDim.x + 7 - xcd) >> 3;
     const unsigned q8 = items >> 3, r8 = items & 7;
     const unsigned range0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -381,9 +447,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
 // slots, removed in round 3; a variant with dedicated staging waves ran 2x slower).  Registers of stage q+1 are published to LDS during taps 0-3 (inputs) and
 // 4-8 (weights) of stage q and refilled at once with the loads of stage q+2, so the staging registers are not doubled.
 // VEC: 0 = scalar staging (any view), 1 = vector staging of a plain view, 2 = vector staging of a pixel-unshuffle view
-template <int MT, bool ACT_IN, int VEC>
+// WIDE: the workgroup tile is 8 rows x 64 pixels (a wave = one row, its two N tiles side by side) instead of 16 x 32 (a wave = two
+// rows): a wave then owns 256 contiguous bytes of every output channel row, and the epilogue (conv2_epilogue_wide) writes them as
+// 4 channels x 256 B per instruction instead of 8 channels x 128 B -- the CU's store path takes a 256-byte run at the price of a
+// 128-byte one (tools/micro/store_micro.hip: 26.5 vs 13.5 B/clk), and the output burst of a tile was 15 % of the training step.
+template <int MT, bool ACT_IN, int VEC, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p) {
-    constexpr int KS = 3, T = 9, PAD = 1, NW = 8, TH = 2 * NW, TW = 32, NTHR = NW * 64;
+    constexpr int KS = 3, T = 9, PAD = 1, NW = 8, TH = WIDE ? NW : 2 * NW, TW = WIDE ? 64 : 32, NTHR = NW * 64;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
     constexpr int MP = MT * 32, NOCT = 2, NPOS = IH * IW, NX = NOCT * NPOS;
     constexpr int WVEC = T * NOCT * MP;  // 16-byte vectors per weight part (hi or lo)
@@ -401,8 +471,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     const int nchunks = (Ctot + 15) / 16;
 
     // persistent schedule as in conv_fwd2_kernel: 8 contiguous item ranges, one per XCD
-    const unsigned nmb = (p.Co + MP - 1) / MP, nty = (p.Hout + TH - 1) / TH;
-    const unsigned items = p.ntx * nty * nmb * p.B;
+    const unsigned nmb = (p.Co + MP - 1) / MP, nty = (p.Hout + TH - 1) / TH, ntx = (p.Wout + TW - 1) / TW;
+    const unsigned items = ntx * nty * nmb * p.B;
     const unsigned xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, nwq = (gridDim.x + 7 - xcd) >> 3;
     const unsigned q8 = items >> 3, r8 = items & 7;
     const unsigned range0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -416,11 +486,11 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     auto tile_of = [&](int k) {
         const unsigned S = S0 + (unsigned)k * nwq;
         Tile t;
-        const unsigned u = S % (p.ntx * nty);
-        t.x0 = (int)(u % p.ntx) * TW;
-        t.y0 = (int)(u / p.ntx) * TH;
-        t.mb = (int)((S / (p.ntx * nty)) % nmb);
-        t.b = (int)(S / (p.ntx * nty * nmb));
+        const unsigned u = S % (ntx * nty);
+        t.x0 = (int)(u % ntx) * TW;
+        t.y0 = (int)(u / ntx) * TH;
+        t.mb = (int)((S / (ntx * nty)) % nmb);
+        t.b = (int)(S / (ntx * nty * nmb));
         return t;
     };
 
@@ -429,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     // load instructions and address arithmetic of the scalar path.  The 10 groups of a row cover 40 pixels of which
     // the tile uses 34 (groups 0 and 9 contribute one pixel each).  All loads are unconditional (clamped addresses,
     // validity applied at the LDS write), see conv_fwd2_kernel.
-    constexpr int NG = 10;
+    constexpr int NG = TW / 4 + 2;   // 4-pixel groups of a staged row: x0 - 4 .. x0 + TW + 3
     // buffer views (VEC staging): the packed weight image, and the current tile's batch element of each input / of act'
     __amdgpu_buffer_rsrc_t w_rs = buf_view_2g(p.wpack), xa_rs = buf_view_2g(va.p), xb_rs = buf_view_2g(va.p), act_rs = buf_view_2g(va.p);
     constexpr int NIT = VEC ? 1 : (NX + NTHR - 1) / NTHR;  // input items per thread
@@ -715,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int idx = (hi * IH + wave * 2 + n + dy) * IW + lo + dx;
+                const int idx = WIDE ? (hi * IH + wave + dy) * IW + lo + 32 * n + dx : (hi * IH + wave * 2 + n + dy) * IW + lo + dx;
                 bh[slot][n] = xs_hi[idx];
                 bl[slot][n] = xs_lo[idx];
             }
@@ -762,7 +832,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         if (last_chunk) {  // last chunk of tile k: epilogue, fresh accumulators
             const Tile cur = tile_of(k);
             const float* bias_s = bias_base + (k & 3) * MP;
-            if (p.ps)
+            if (WIDE) {   // (launch_fwd5: 16-byte stores, no pixel shuffle, one output tensor)
+                if (p.res != nullptr) conv2_epilogue_wide<MT, 1>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave, cur.x0, lo, hi);
+                else conv2_epilogue_wide<MT, 0>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave, cur.x0, lo, hi);
+            } else if (p.ps)
                 conv2_epilogue<MT, 3>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
             else if (p.out2 != nullptr)
                 conv2_epilogue<MT, 2>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
@@ -851,11 +924,24 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
                                   : vec ? conv_fwd5_kernel<MT, true, 1> : conv_fwd5_kernel<MT, true, 0>)
                                : (vec == 3 ? conv_fwd5_kernel<MT, false, 3> : vec == 2 ? conv_fwd5_kernel<MT, false, 2>
                                   : vec ? conv_fwd5_kernel<MT, false, 1> : conv_fwd5_kernel<MT, false, 0>);
-    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd5: cannot reserve %zu B of LDS", lds);
-    const int nty = (p.Hout + 15) / 16;
-    const long items = (long)p.ntx * nty * ((p.Co + MT * 32 - 1) / (MT * 32)) * p.B;
+    // tile shape: 8 x 64 (256-byte output runs, 16-byte stores, plain vector-staged view) when it wastes no more pixels than 16 x 32
+    int th = 16, tw = 32;
+    size_t lds_k = lds;
+    if constexpr (MT == 2) {
+        static const int wide_ok = [] { const char* e = getenv("RVSR_CONV_WIDE"); return e ? atoi(e) : 1; }();   // developer A/B switch
+        const long px_n = (long)((p.Hout + 15) / 16 * 16) * ((p.Wout + 31) / 32 * 32), px_w = (long)((p.Hout + 7) / 8 * 8) * ((p.Wout + 63) / 64 * 64);
+        if (wide_ok && vec == 1 && p.vec4 && px_w <= px_n) {
+            k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true> : conv_fwd5_kernel<MT, false, 1, true>;
+            th = 8; tw = 64;
+            constexpr int NXW = 2 * 10 * 66;
+            lds_k = (size_t)16 * (2 * 2 * NXW + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32 + 16;
+        }
+    }
+    if (set_lds(k, lds_k)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd5: cannot reserve %zu B of LDS", lds_k);
+    const int nty = (p.Hout + th - 1) / th;
+    const long items = (long)((p.Wout + tw - 1) / tw) * nty * ((p.Co + MT * 32 - 1) / (MT * 32)) * p.B;
     dim3 grid((unsigned)(items < 256 ? items : 256), 1, 1);
-    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds_k, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "conv_fwd5 launch: %s", hipGetErrorString(e));
     return RVSR_OK;

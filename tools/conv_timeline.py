@@ -12,8 +12,8 @@ buf = (ctypes.c_ulonglong * 256)()
 print('rc', L.rvsr_debug_read(buf))
 t = list(buf)
 names = {0: 'tile start'}
-V3 = os.environ.get('RVSR_CONV_FWD', '5') != '2'
-V5 = os.environ.get('RVSR_CONV_FWD', '5') == '5'
+V3 = True   # (round 3: conv_fwd5 is the only 3x3 stride-1 kernel)
+V5 = True
 if V3:
     # conv_fwd3_kernel: stamps of the last 8 slots of workgroup 77, wave 0 (group A: even slots MFMA, odd slots staging)
     names = {}
