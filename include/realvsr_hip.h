@@ -87,21 +87,27 @@ int rvsr_modulated_deform_conv_backward(const float* input, const float* weight,
  * (B,3*dg*9,Ho,Wo) output of conv_offset_mask; torch.chunk/torch.cat become addressing (channels
  * [0,2*dg*9) are the offsets, the rest mask logits) and torch.sigmoid runs in-kernel.
  * act: 0 none, 1 ReLU, 2 LeakyReLU(slope) applied to the output (EDVR_arch.py:107,130); act | 0x100: `workspace`
- * already holds this layer's packed weight image (rvsr_dcn_pack_weights / rvsr_pack_weights_batched), skip the per-call pack. */
+ * already holds this layer's packed weight image (rvsr_dcn_pack_weights / rvsr_pack_weights_batched), skip the per-call pack.
+ * probe (NULL or 8 zeroed uint32 on the device): receives the sampled offset statistic (components beyond 2.5 .. 11.5 px) from
+ * which the forward picks the halo of its LDS tile on the device (3 / 7 / 11 px, no host round trip); hand the same buffer to
+ * rvsr_dcn_pack_backward, which then skips its own probe pass.  NULL: the halo in act bits 10..13 (3 / 7 / 11, chosen by the caller
+ * from an earlier statistic, rvsr_dcn_offset_probe), else 3 px; out-of-tile samples gather from global memory in every case. */
+int rvsr_dcn_offset_probe(const float* om, int batch, int height_out, int width_out, int deformable_group, void* probe, void* stream);
 size_t rvsr_dcn_pack_weights(const float* weight, int channels, int channels_out, void* out, size_t out_bytes,
                              long long* desc, void* stream);
 int rvsr_dcn_pack_forward(const float* input, const float* weight, const float* bias, const float* om,
                           float* output, int batch, int channels, int height, int width, int channels_out,
                           int stride, int pad, int dilation, int deformable_group, int act, float slope,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          void* probe, void* workspace, size_t workspace_bytes, void* stream);
 /* act_out (NULL or the saved activation output) fuses the activation derivative into the
  * grad_output load.  grad_om (B,3*dg*9,Ho,Wo) is overwritten (d/d logit for the mask part);
- * grad_input zero on entry; grad_weight/grad_bias accumulated. */
+ * grad_input zero on entry; grad_weight/grad_bias accumulated.
+ * probe: NULL, or the counters rvsr_dcn_pack_forward filled for the same `om`. */
 int rvsr_dcn_pack_backward(const float* input, const float* weight, const float* om, const float* grad_output,
                            const float* act_out, float act_slope, float* grad_input, float* grad_weight,
                            float* grad_bias, float* grad_om, int batch, int channels, int height, int width,
                            int channels_out, int stride, int pad, int dilation, int deformable_group,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           const void* probe, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 2. Convolution blocks (nn.Conv2d 3x3 / 1x1, padding = ksize/2) with fused neighbours

@@ -235,7 +235,7 @@ extern "C" size_t rvsr_dcn_pack_weights(const float* weight, int C, int Co, void
     return need;
 }
 
-int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st, const unsigned* probe, size_t nprobe, int halo_hint) {
     const DcnGeom& d = p.d;
     if (d.cpg % 8 != 0) return RVSR_ERR_UNSUPPORTED;  // a k-octet must lie inside one deformable group
     int mt, nchunks, nmb;
@@ -249,7 +249,7 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
     const bf16x8* wp = (const bf16x8*)workspace;
     static const int gen = [] { const char* e = getenv("RVSR_DCN_FWD"); return e ? atoi(e) : 3; }();  // developer A/B switch
     if (gen >= 3) {
-        const int rc = rvsr_launch_dcn_fwd3(p, workspace, mt, st);
+        const int rc = rvsr_launch_dcn_fwd3(p, workspace, mt, st, probe, nprobe, halo_hint);
         if (rc != RVSR_ERR_UNSUPPORTED) return rc;
     }
     if (mt == 1) return launch_dcn_fwd2<8, 1>(p, wp, st);

@@ -92,10 +92,15 @@ __device__ __forceinline__ f32x2 blend4(f32x2 s, f32x2 t, f32x2 a00, f32x2 a01, 
     return r;
 }
 
-template <int MT>
-__global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
+// R: halo of the LDS x tile beyond the 3x3 footprint.  R = 3 is the kernel of round 2 (two workgroups per CU).  R = 7 / 11 (one
+// workgroup per CU, a 24 x 48 / 32 x 56 tile) are launched next to it when the caller passes probe counters of the offsets
+// (rvsr_launch_dcn_fwd3): every candidate returns at once unless the counters select it, so that px-scale offsets sample from LDS
+// instead of gathering from global memory lane by lane (3 px mean |offset|: 0.19 -> see profiles/r03_notes.md).  pad + R is a
+// multiple of 4 for all three: tile rows start on 16-byte boundaries and the large tiles are staged with 16-byte loads.
+template <int MT, int R>
+__global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
-    constexpr int TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2, NPOS = TR * TC;
+    constexpr int TR = TH + 2 * R + 2, TC = 32 + 2 * R + 2, NPOS = TR * TC;
     constexpr int MP = MT * 32, WVEC = 9 * 2 * MP;  // 16-byte vectors per weight part
     constexpr int NWV = (2 * WVEC + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -104,12 +109,13 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
     bf16x8* ws_lo = ws_hi + WVEC;
     float* bias_s = reinterpret_cast<float*>(ws_lo + WVEC);     // [MP]
     const DcnGeom& d = p.d;
+    if (dcn_halo_not_selected(p.sel)) return;   // (uniform) not the halo the offsets of this call ask for
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     unsigned sbx, sby, sbz;
     swizzled_block(sbx, sby, sbz, d.swz);
     const int tx = sbx % d.ntx, ty = sbx / d.ntx;
     const int x0 = tx * 32, y0 = ty * TH, mb = sby, b = sbz;
-    const int ty0 = y0 - d.pad - D2_R, tx0 = x0 - d.pad - D2_R;  // image coords of tile (0,0); stride 1
+    const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;  // image coords of tile (0,0); stride 1
     const int nchunks = (d.C + 15) / 16;
     const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
     const int oy = y0 + wave, ox = x0 + lo;
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
     const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs);
     const __amdgpu_buffer_rsrc_t msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
     const __amdgpu_buffer_rsrc_t x_rs = buf_view(d.x + (size_t)b * d.C * HW), out_rs = buf_view(p.out + (size_t)b * d.Co * hw);
+    const __amdgpu_buffer_rsrc_t x2g_rs = buf_view_2g(d.x + (size_t)b * d.C * HW);   // (large tiles: bit 31 of a lane offset = "reads zero")
 
     f32x16 acc[MT];
 #pragma unroll
@@ -152,13 +159,52 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e),
                                                      (__attribute__((address_space(3))) void*)(ws_hi + e), 16, 0, 0);
             }
-            static_assert(TR == 16 && TC == 40 && NT == 512, "xtile16x40 is written for this tile");
-            XTile16x40 xr;
-            xtile16x40_load(xr, d, x_rs, c0, ty0, tx0, tid);
-            TSTAMP(1 + 6 * chunk);
-            TSTAMP(2 + 6 * chunk);
-            xtile16x40_commit(xt, xr, d, c0, tid);
-            TSTAMP(3 + 6 * chunk);
+            if constexpr (R == 3) {
+                static_assert(R != 3 || (TR == 16 && TC == 40 && NT == 512), "xtile16x40 is written for this tile");
+                XTile16x40 xr;
+                xtile16x40_load(xr, d, x_rs, c0, ty0, tx0, tid);
+                TSTAMP(1 + 6 * chunk);
+                TSTAMP(2 + 6 * chunk);
+                xtile16x40_commit(xt, xr, d, c0, tid);
+                TSTAMP(3 + 6 * chunk);
+            } else {
+                // item = (quad, row, group of 4 columns): four 16-byte loads (one per channel of the quad) land as the float4s of four
+                // positions -- a renaming of registers, no shuffles.  Rows / column groups outside the image and channels beyond C read
+                // zeros through the buffer range check (lane offset beyond the 2 GB view); W % 4 == 0 (launcher) keeps a group whole.
+                constexpr int TC4 = TC / 4, NITEM = 4 * TR * TC4, NXI = (NITEM + NT - 1) / NT;
+                static_assert(TC % 4 == 0, "tile rows are whole 16-byte groups");
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                const unsigned HW4b = 4u * (unsigned)(d.H * d.W);
+                f32x4v xv[NXI][4];
+#pragma unroll
+                for (int k = 0; k < NXI; ++k) {
+                    const int it = tid + k * NT;
+                    const int q = it / (TR * TC4), rem = it - q * (TR * TC4);
+                    const int r = rem / TC4, g4 = rem - r * TC4;
+                    const int gy = ty0 + r, gx = tx0 + 4 * g4;
+                    const bool ok = it < NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+                    const unsigned off = ok ? 4u * (unsigned)(gy * d.W + gx) : 0x80000000u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = c0 + 4 * q + e;
+                        xv[k][e] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(x2g_rs, (int)(c < d.C ? off : 0x80000000u),
+                                                                                                  (int)((unsigned)(c < d.C ? c : 0) * HW4b), 0));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NXI; ++k) {
+                    const int it = tid + k * NT;
+                    if (it < NITEM) {
+                        const int q = it / (TR * TC4), rem = it - q * (TR * TC4);
+                        const int r = rem / TC4, g4 = rem - r * TC4;
+                        float4* dst = xt + q * NPOS + r * TC + 4 * g4;
+                        dst[0] = make_float4(xv[k][0].x, xv[k][1].x, xv[k][2].x, xv[k][3].x);
+                        dst[1] = make_float4(xv[k][0].y, xv[k][1].y, xv[k][2].y, xv[k][3].y);
+                        dst[2] = make_float4(xv[k][0].z, xv[k][1].z, xv[k][2].z, xv[k][3].z);
+                        dst[3] = make_float4(xv[k][0].w, xv[k][1].w, xv[k][2].w, xv[k][3].w);
+                    }
+                }
+            }
             if (chunk == 0 && tid < MP) {
                 const int o = mb * MP + tid;
                 bias_s[tid] = (p.bias != nullptr && o < d.Co) ? p.bias[o] : 0.f;
@@ -290,11 +336,11 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn_fwd3_kernel(const Dc
     TSTAMP(30);
 }
 
-template <int MT>
+template <int MT, int R>
 static int launch_dcn_fwd3(const DcnFwdParams& p, const bf16x8* wpack, hipStream_t st) {
-    constexpr int TH = 8, TR = TH + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
+    constexpr int TH = 8, TR = TH + 2 * R + 2, TC = 32 + 2 * R + 2;
     const size_t lds = (size_t)16 * (4 * TR * TC + 2 * 9 * 2 * MT * 32) + sizeof(float) * MT * 32;
-    auto k = dcn_fwd3_kernel<MT>;
+    auto k = dcn_fwd3_kernel<MT, R>;
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd3: cannot reserve %zu B of LDS", lds);
     const DcnGeom& d = p.d;
     dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), (d.Co + MT * 32 - 1) / (MT * 32), d.B);
@@ -303,16 +349,56 @@ static int launch_dcn_fwd3(const DcnFwdParams& p, const bf16x8* wpack, hipStream
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd3 launch: %s", hipGetErrorString(e));
     return RVSR_OK;
 }
+template <int MT>
+static int launch_dcn_fwd3_halo(const DcnFwdParams& p, const bf16x8* wpack, int halo, hipStream_t st) {
+    if (halo <= 3) return launch_dcn_fwd3<MT, 3>(p, wpack, st);
+    if (halo <= 7) return launch_dcn_fwd3<MT, 7>(p, wpack, st);
+    if constexpr (MT <= 2) return launch_dcn_fwd3<MT, 11>(p, wpack, st);   // (11 px + the 74 KB weight slice of MT = 4 exceed 160 KB)
+    return launch_dcn_fwd3<MT, 7>(p, wpack, st);
+}
 
-// `wpack`: the image pack_weights_kernel(mode 0, CCG 1) wrote for (mt, nchunks, nmb) -- built by rvsr_launch_dcn_fwd2's caller
-int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st) {
+// `wpack`: the image pack_weights_kernel(mode 0, CCG 1) wrote for (mt, nchunks, nmb) -- built by rvsr_launch_dcn_fwd2's caller.
+// `probe` (nullable): the three device counters of dcn_offset_probe2_kernel for this call's offsets: the halo is then chosen on the device.
+int rvsr_launch_dcn_fwd3(const DcnFwdParams& p_in, const void* wpack, int mt, hipStream_t st, const unsigned* probe, size_t nprobe, int halo_hint) {
+    DcnFwdParams p = p_in;
     const DcnGeom& d = p.d;
     if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
     // 32-bit byte offsets into one batch element's x / offset / output planes: larger frames take dcn_fwd2
     const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)(d.C > d.Co ? d.C : d.Co) ? (size_t)(d.C / d.cpg) * 18 : (size_t)(d.C > d.Co ? d.C : d.Co);
     if (planes * d.H * d.W * sizeof(float) >= ((size_t)1 << 32)) return RVSR_ERR_UNSUPPORTED;
     const bf16x8* wp = (const bf16x8*)wpack;
-    if (mt == 1) return launch_dcn_fwd3<1>(p, wp, st);
-    if (mt == 2) return launch_dcn_fwd3<2>(p, wp, st);
-    return launch_dcn_fwd3<4>(p, wp, st);
+    static const int fixed = [] { const char* e = getenv("RVSR_DCN3_HALO"); return e ? atoi(e) : -1; }();   // developer A/B switch
+    const bool big_ok = (d.W % 4 == 0) && ((((uintptr_t)d.x) & 15) == 0) && (size_t)d.C * d.H * d.W * sizeof(float) < ((size_t)1 << 31);
+    p.sel = dcn_halo_always();
+    int rc = RVSR_OK;
+#define FWD3_DISPATCH(HALO)                                                        \
+    do {                                                                           \
+        if (mt == 1) rc = launch_dcn_fwd3_halo<1>(p, wp, HALO, st);                \
+        else if (mt == 2) rc = launch_dcn_fwd3_halo<2>(p, wp, HALO, st);           \
+        else rc = launch_dcn_fwd3_halo<4>(p, wp, HALO, st);                        \
+    } while (0)
+    if (fixed >= 0 || probe == nullptr || !big_ok) {
+        // no counters: the caller's hint (a halo chosen on the host from an earlier statistic of this layer's offsets), else 3 px
+        FWD3_DISPATCH(big_ok ? (fixed >= 0 ? fixed : (halo_hint > 0 ? halo_hint : 3)) : 3);
+        return rc;
+    }
+    // The smallest tile that leaves (almost) no sample outside: a k-step in which ANY of a wave's 64 lanes left the tile pays the global
+    // gather for all of them, and at one workgroup per CU the large tiles hide that latency worse than the small one -- measured
+    // (profiles/r03_notes.md): a 7 px halo with 10 % of the samples outside is slower than the 3 px halo with 65 % outside.
+    //   R = 3: < 8 % of the offset components beyond 3.5 px;  R = 7: else, < 1 % beyond 7.5 px (or no larger tile);  R = 11: the rest
+    // (crossovers of the fixed-halo timings at offset std 1.25 / 2.5 / 3.75 / 6.25 px; functional.dcn_forward_halo applies the same rule
+    // on the host to the counters of the previous step).
+    const unsigned thr3 = (unsigned)(nprobe * 8 / 100) + 1, thr7 = (unsigned)(nprobe / 100) + 1;
+    const bool has11 = mt <= 2;
+    p.sel.probe = probe;
+    p.sel.ge = -1; p.sel.lt = 1; p.sel.thr_lt = thr3;
+    FWD3_DISPATCH(3);
+    if (rc != RVSR_OK) return rc;
+    p.sel.ge = 1; p.sel.thr_ge = thr3; p.sel.lt = has11 ? 3 : -1; p.sel.thr_lt = thr7;
+    FWD3_DISPATCH(7);
+    if (rc != RVSR_OK || !has11) return rc;
+    p.sel.ge = 3; p.sel.thr_ge = thr7; p.sel.lt = -1;
+    FWD3_DISPATCH(11);
+#undef FWD3_DISPATCH
+    return rc;
 }

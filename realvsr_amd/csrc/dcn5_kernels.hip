@@ -51,10 +51,7 @@ struct DcnBwdIn5Params {
     float* goff;
     float* gmask;
     size_t goff_bs, gmask_bs;
-    // Kernel selection on the device: every candidate halo is launched and returns at once unless the probe's two counters
-    // (offset components beyond 2.5 / 5.5 / 8.5 px) lie in its ranges.  nullptr: always run.
-    const unsigned* probe;
-    unsigned lo[3], hi[3];         // run when lo[i] <= probe[i] < hi[i] for i = 0, 1, 2
+    DcnHaloSel sel;     // kernel selection on the device (dcn_common.h): every candidate halo is launched, one runs
     const float* wnorm;            // [chunk]: max over the chunk's 72 (tap, channel) columns of ||W[:, c, tap]||_2
 };
 
@@ -113,13 +110,14 @@ __global__ void pack_weights_bwd5_kernel(const float* __restrict__ w, bf16x8* __
     }
 }
 
-// Sampled statistic behind the halo selection: every 16th row of every offset plane; cnt[0 / 1 / 2] = components with
-// |v| > 2.5 / 5.5 / 8.5 px (what the R = 2 / 5 / 8 tiles do not cover on either side).
+// Sampled statistic behind the halo selection of both DCN directions: every 16th row of every offset plane;
+// cnt[0..5] = components with |v| > 2.5 / 3.5 / 5.5 / 7.5 / 8.5 / 11.5 px (DcnHaloSel).
 __global__ void dcn_offset_probe2_kernel(const float* __restrict__ off, size_t off_bs, int B, int planes, int Ho, int Wo,
                                          unsigned* __restrict__ cnt) {
     const int nrow = (Ho + 15) / 16;
     const size_t total = (size_t)B * planes * nrow * Wo;
-    unsigned a = 0, c = 0, e8 = 0;
+    const float lim[DCN_PROBE_COUNTERS] = {2.5f, 3.5f, 5.5f, 7.5f, 8.5f, 11.5f};
+    unsigned n[DCN_PROBE_COUNTERS] = {0, 0, 0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % Wo);
         size_t r = i / Wo;
@@ -128,20 +126,24 @@ __global__ void dcn_offset_probe2_kernel(const float* __restrict__ off, size_t o
         const int pl = (int)(r % planes), b = (int)(r / planes);
         const int y = row * 16 + 8 < Ho ? row * 16 + 8 : Ho - 1;
         const float v = fabsf(off[(size_t)b * off_bs + ((size_t)pl * Ho + y) * Wo + x]);
-        a += v > 2.5f ? 1u : 0u;
-        c += v > 5.5f ? 1u : 0u;
-        e8 += v > 8.5f ? 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < DCN_PROBE_COUNTERS; ++k) n[k] += v > lim[k] ? 1u : 0u;
     }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        a += __shfl_xor(a, s);
-        c += __shfl_xor(c, s);
-        e8 += __shfl_xor(e8, s);
-    }
+    for (int k = 0; k < DCN_PROBE_COUNTERS; ++k)
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) n[k] += __shfl_xor(n[k], s);
+    // one atomic per counter and BLOCK (per wave, 2 K blocks x 4 waves on the same few addresses took 226 us at 3 px offsets)
+    __shared__ unsigned part[DCN_PROBE_COUNTERS][4];
+    const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        if (a) atomicAdd(cnt, a);
-        if (c) atomicAdd(cnt + 1, c);
-        if (e8) atomicAdd(cnt + 2, e8);
+#pragma unroll
+        for (int k = 0; k < DCN_PROBE_COUNTERS; ++k) part[k][wv] = n[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < DCN_PROBE_COUNTERS) {
+        const unsigned t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        if (t) atomicAdd(cnt + threadIdx.x, t);
     }
 }
 
@@ -175,13 +177,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
     int* gwin = reinterpret_cast<int*>(xt + 2 * NPOS);             // [8 channels][NPOS]: the grad_input tile of this chunk, fixed point
     bf16x8* wsb = reinterpret_cast<bf16x8*>(gwin + 8 * NPOS);      // [3][WBLK]
     float* gn_red = reinterpret_cast<float*>(wsb + 3 * WBLK);      // [8 waves]: largest ||gOut[:, px]||^2 of the wave's row
-    if (p.probe != nullptr) {   // (uniform) not the halo the offsets of this call ask for
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const unsigned c_ = p.probe[i];
-            if (c_ < p.lo[i] || c_ >= p.hi[i]) return;
-        }
-    }
+    if (dcn_halo_not_selected(p.sel)) return;   // (uniform) not the halo the offsets of this call ask for
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     unsigned sbx, sby, sbz;
@@ -453,9 +449,18 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
     }
 }
 
+// memset-free: the caller zeroes the three counters (a fresh torch.zeros in the Python layer, hipMemsetAsync in the backward's own path)
+size_t rvsr_launch_dcn_offset_probe(const DcnGeom& d, unsigned* cnt, hipStream_t st) {
+    const int oplanes = (d.C / d.cpg) * 18, nrow = (d.Ho + 15) / 16;
+    const size_t nprobe = (size_t)d.B * oplanes * nrow * d.Wo;
+    const unsigned nb = (unsigned)((nprobe + 2047) / 2048 < 2048 ? (nprobe + 2047) / 2048 : 2048);
+    hipLaunchKernelGGL(dcn_offset_probe2_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, d.offset, d.off_bs, d.B, oplanes, d.Ho, d.Wo, cnt);
+    return nprobe;
+}
+
 static int nk5_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : (Co <= 64 ? 4 : 8)); }
 size_t rvsr_dcn_bwdin5_workspace_bytes(int Co, int C) {
-    // weight image + per-chunk column norms + the probe's two counters
+    // weight image + per-chunk column norms + the probe's counters
     return (size_t)((C + 7) / 8) * 3 * 2 * (2 * nk5_of(Co)) * 32 * 16 + (((size_t)((C + 7) / 8) * 4 + 255) & ~(size_t)255) + 256;
 }
 
@@ -484,7 +489,8 @@ static int launch_bwdin5_halo(const DcnBwdIn5Params& p, const bf16x8* wpack, int
 
 // halo < 0: selected on the device from the offsets (probe + one launch per candidate halo, no host round trip)
 int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo) {
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo,
+                           const unsigned* probe_in) {
     if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin5_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     // 32-bit byte offsets into one batch element's planes (x through a 2 GB view: bit 31 marks the zero padding)
@@ -507,8 +513,7 @@ int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g
     }
     DcnBwdIn5Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
-    p.probe = nullptr; p.wnorm = wnorm;
-    for (int i = 0; i < 3; ++i) { p.lo[i] = 0; p.hi[i] = 0xffffffffu; }
+    p.sel = dcn_halo_always(); p.wnorm = wnorm;
 #define BWDIN5_DISPATCH(HALO)                                                   \
     switch (NK) {                                                               \
         case 1: rc = launch_bwdin5_halo<1>(p, wpack, HALO, st); break;          \
@@ -521,23 +526,26 @@ int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g
         BWDIN5_DISPATCH(halo);
         return rc;
     }
-    if (hipMemsetAsync(cnt, 0, 3 * sizeof(unsigned), st) != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward: memset of the probe counters failed");
     const int oplanes = (d.C / d.cpg) * 18, nrow = (d.Ho + 15) / 16;
     const size_t nprobe = (size_t)d.B * oplanes * nrow * d.Wo;
-    const unsigned nb = (unsigned)((nprobe + 2047) / 2048 < 2048 ? (nprobe + 2047) / 2048 : 2048);
-    hipLaunchKernelGGL(dcn_offset_probe2_kernel, dim3(nb ? nb : 1), dim3(256), 0, st, d.offset, d.off_bs, d.B, oplanes, d.Ho, d.Wo, cnt);
+    if (probe_in != nullptr) {
+        cnt = const_cast<unsigned*>(probe_in);   // the forward of this layer already counted these offsets (rvsr_dcn_pack_forward's probe)
+    } else {
+        if (hipMemsetAsync(cnt, 0, DCN_PROBE_COUNTERS * sizeof(unsigned), st) != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward: memset of the probe counters failed");
+        rvsr_launch_dcn_offset_probe(d, cnt, st);
+    }
     // A sample beyond the halo costs 16 global gathers + 16 global atomics (~50x an in-tile sample), a larger halo costs
     // staging and flush work in proportion to its cells (585 / 945 / 1377 / 2065): switch up as soon as a few percent of the
     // offset components leave the smaller tile.
     static const int pct = [] { const char* e = getenv("RVSR_DCN5_PCT"); return e ? atoi(e) : 2; }();   // developer A/B switch
-    const unsigned thr = (unsigned)(nprobe * (size_t)pct / 100) + 1, inf = 0xffffffffu;
+    const unsigned thr = (unsigned)(nprobe * (size_t)pct / 100) + 1;
     const bool has12 = NK <= 4;
-    p.probe = cnt;
+    p.sel.probe = cnt;
+    p.sel.thr_ge = p.sel.thr_lt = thr;
     // R = 2: few components beyond 2.5 px; R = 5: else, few beyond 5.5; R = 8: else, few beyond 8.5 (or no larger tile); R = 12: the rest
-    const unsigned sel[4][6] = {{0, thr, 0, inf, 0, inf}, {thr, inf, 0, thr, 0, inf}, {thr, inf, thr, inf, 0, has12 ? thr : inf}, {thr, inf, thr, inf, thr, inf}};
-    const int halos[4] = {2, 5, 8, 12};
+    const int halos[4] = {2, 5, 8, 12}, ge[4] = {-1, 0, 2, 4}, lt[4] = {0, 2, has12 ? 4 : -1, -1};
     for (int k = 0; k < (has12 ? 4 : 3); ++k) {
-        for (int i = 0; i < 3; ++i) { p.lo[i] = sel[k][2 * i]; p.hi[i] = sel[k][2 * i + 1]; }
+        p.sel.ge = ge[k]; p.sel.lt = lt[k];
         BWDIN5_DISPATCH(halos[k]);
         if (rc != RVSR_OK) return rc;
     }

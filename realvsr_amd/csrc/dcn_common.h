@@ -69,6 +69,24 @@ __device__ __forceinline__ Samp dcn_sample(const DcnGeom& d, int b, int g, int k
 }
 
 
+// Device-side choice among tile halos: every candidate kernel is launched and returns at once unless
+//   (ge < 0 || probe[ge] >= thr_ge) && (lt < 0 || probe[lt] < thr_lt)
+// probe[0..5] = sampled counts of offset components with |v| > 2.5 / 3.5 / 5.5 / 7.5 / 8.5 / 11.5 px (dcn_offset_probe2_kernel): the
+// backward's windows (2 / 5 / 8 / 12 px) use counters 0, 2, 4, the forward's tiles (3 / 7 / 11 px) counters 1, 3, 5.  probe == nullptr: run.
+#define DCN_PROBE_COUNTERS 6
+struct DcnHaloSel {
+    const unsigned* probe;
+    int ge, lt;
+    unsigned thr_ge, thr_lt;
+};
+__device__ __forceinline__ bool dcn_halo_not_selected(const DcnHaloSel& s) {
+    if (s.probe == nullptr) return false;
+    if (s.ge >= 0 && s.probe[s.ge] < s.thr_ge) return true;
+    if (s.lt >= 0 && s.probe[s.lt] >= s.thr_lt) return true;
+    return false;
+}
+static inline DcnHaloSel dcn_halo_always() { DcnHaloSel s; s.probe = nullptr; s.ge = s.lt = -1; s.thr_ge = s.thr_lt = 0; return s; }
+
 struct DcnFwdParams {
     DcnGeom d;
     const float* w;     // (Co, C, 3, 3)
@@ -77,14 +95,19 @@ struct DcnFwdParams {
     int act;
     float slope;
     int prepacked;      // the workspace already holds the packed weight image (rvsr_dcn_pack_weights / rvsr_pack_weights_batched)
+    DcnHaloSel sel;     // halo selection on the device (dcn_fwd3_kernel<MT, R>)
 };
 
 
 // bf16x3 forward (dcn2_kernels.hip); returns RVSR_ERR_UNSUPPORTED if the geometry is not covered
 size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C);
-int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st);
+int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspace_bytes, hipStream_t st, const unsigned* probe = nullptr,
+                         size_t nprobe = 0, int halo_hint = 0);
 // third-generation forward (dcn3_kernels.hip): consumes the weight image rvsr_launch_dcn_fwd2 packs; stride 1, dilation 1
-int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st);
+int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st, const unsigned* probe = nullptr, size_t nprobe = 0,
+                         int halo_hint = 0);
+// the three-counter offset statistic both DCN directions select their tile halo from (dcn5_kernels.hip); returns the sample count
+size_t rvsr_launch_dcn_offset_probe(const DcnGeom& d, unsigned* cnt, hipStream_t st);
 size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
@@ -101,5 +124,6 @@ int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TVie
 // fifth-generation input / offset / mask gradient (dcn5_kernels.hip): shared f64 LDS window; halo < 0 = chosen on the device
 size_t rvsr_dcn_bwdin5_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1);
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1,
+                           const unsigned* probe_in = nullptr);
 extern int rvsr_g_gemm_mode;

@@ -378,11 +378,16 @@ static int fill_geom(DcnGeom& d, const float* x, const float* offset, size_t off
 }
 
 static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, float* out, int act, float slope,
-                            void* workspace, size_t workspace_bytes, hipStream_t st, int prepacked = 0) {
+                            void* workspace, size_t workspace_bytes, hipStream_t st, int prepacked = 0, unsigned* probe = nullptr, int halo_hint = 0) {
     DcnFwdParams p;
     p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act & 0xff; p.slope = slope; p.prepacked = prepacked;
+    p.sel = dcn_halo_always();
     if (rvsr_g_gemm_mode == 0 && workspace != nullptr) {  // bf16x3 second-generation kernel
-        const int rc = rvsr_launch_dcn_fwd2(p, workspace, workspace_bytes, st);
+        // `probe`: three zeroed device counters; filled with the offset statistic that selects the tile halo on the device (and that
+        // the backward of the same layer reuses)
+        size_t nprobe = 0;
+        if (probe != nullptr && d.cpg % 8 == 0 && d.stride == 1 && d.dil == 1) nprobe = rvsr_launch_dcn_offset_probe(d, probe, st);
+        const int rc = rvsr_launch_dcn_fwd2(p, workspace, workspace_bytes, st, nprobe ? probe : nullptr, nprobe, halo_hint);
         if (rc != RVSR_ERR_UNSUPPORTED) return rc;
     }
     const int nty = (d.Ho + 3) / 4;
@@ -437,7 +442,7 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
 
 static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout, const float* gact, float gact_slope,
                              float* gx, float* goff, size_t goff_bs, float* gmask, size_t gmask_bs, float* gw, float* gb,
-                             void* workspace, size_t workspace_bytes, hipStream_t st) {
+                             void* workspace, size_t workspace_bytes, hipStream_t st, const unsigned* probe = nullptr) {
     const size_t need = rvsr_modulated_deform_conv_backward_workspace_bytes(d.B, d.C, d.H, d.W, d.Co, d.stride, d.pad, d.dil);
     if (gw && (!workspace || workspace_bytes < need)) FAIL(RVSR_ERR_WORKSPACE, "dcn backward: workspace %zu B < %zu B", workspace_bytes, need);
     TView g;
@@ -449,7 +454,7 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         if (rvsr_g_gemm_mode == 0) {
             static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 6; }();  // developer A/B switch
             static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
-            if (gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo);
+            if (gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 5) rc2 = rvsr_launch_dcn_bwdin_auto(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 3)
                 rc2 = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
@@ -550,7 +555,7 @@ extern "C" int rvsr_modulated_deform_conv_backward(const float* input, const flo
 extern "C" int rvsr_dcn_pack_forward(const float* input, const float* weight, const float* bias, const float* om,
                                      float* output, int batch, int channels, int height, int width, int channels_out,
                                      int stride, int pad, int dilation, int deformable_group, int act, float slope,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     void* probe, void* workspace, size_t workspace_bytes, void* stream) {
     DcnGeom d;
     const char* why = "";
     if (!weight || !output) FAIL(RVSR_ERR_BAD_ARG, "dcn_pack_forward: null weight/output");
@@ -561,14 +566,29 @@ extern "C" int rvsr_dcn_pack_forward(const float* input, const float* weight, co
     d.off_bs = d.mask_bs = (size_t)27 * deformable_group * hw;
     d.mask = om + (size_t)18 * deformable_group * hw;
     // act bit 8: `workspace` already holds the packed weight image (rvsr_dcn_pack_weights), skip the per-call pack
-    return dcn_forward_impl(d, weight, bias, output, act, slope, workspace, workspace_bytes, (hipStream_t)stream, (act >> 8) & 1);
+    // act bits 10..13: halo of the forward's LDS tile chosen by the caller (3 / 7 / 11; 0 = from `probe`, or 3 px without one)
+    return dcn_forward_impl(d, weight, bias, output, act, slope, workspace, workspace_bytes, (hipStream_t)stream, (act >> 8) & 1, (unsigned*)probe,
+                            (act >> 10) & 15);
+}
+
+// The sampled offset statistic on its own (8 zeroed uint32 on the device, 6 used): lets a caller keep the counters, e.g. to choose the
+// forward's halo of the NEXT step on the host without a synchronisation (realvsr_amd.functional), and hand them to the backward.
+extern "C" int rvsr_dcn_offset_probe(const float* om, int batch, int height_out, int width_out, int deformable_group, void* probe, void* stream) {
+    if (!om || !probe || batch <= 0 || deformable_group <= 0) FAIL(RVSR_ERR_BAD_ARG, "dcn_offset_probe: null/empty argument");
+    DcnGeom d;
+    d.offset = om; d.off_bs = (size_t)27 * deformable_group * height_out * width_out;
+    d.B = batch; d.C = 8 * deformable_group; d.cpg = 8; d.Ho = height_out; d.Wo = width_out;
+    rvsr_launch_dcn_offset_probe(d, (unsigned*)probe, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_offset_probe launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
 }
 
 extern "C" int rvsr_dcn_pack_backward(const float* input, const float* weight, const float* om, const float* grad_output,
                                       const float* act_out, float act_slope, float* grad_input, float* grad_weight,
                                       float* grad_bias, float* grad_om, int batch, int channels, int height, int width,
                                       int channels_out, int stride, int pad, int dilation, int deformable_group,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+                                      const void* probe, void* workspace, size_t workspace_bytes, void* stream) {
     DcnGeom d;
     const char* why = "";
     if (!weight || !grad_output) FAIL(RVSR_ERR_BAD_ARG, "dcn_pack_backward: null weight/grad_output");
@@ -580,5 +600,5 @@ extern "C" int rvsr_dcn_pack_backward(const float* input, const float* weight, c
     d.mask = om + (size_t)18 * deformable_group * hw;
     return dcn_backward_impl(d, weight, grad_output, act_out, act_slope, grad_input, grad_om, d.off_bs,
                              grad_om ? grad_om + (size_t)18 * deformable_group * hw : nullptr, d.off_bs, grad_weight, grad_bias,
-                             workspace, workspace_bytes, (hipStream_t)stream);
+                             workspace, workspace_bytes, (hipStream_t)stream, (const unsigned*)probe);
 }

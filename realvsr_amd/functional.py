@@ -519,6 +519,46 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
 
 
 # ------------------------------------------------------------------------------------------ DCN
+class DcnOffsetStats:
+    """Per DCN layer: the sampled offset counters of the last backward (components beyond 2.5 .. 11.5 px), brought to the host with a
+    non-blocking copy + event, so that the NEXT forward of the layer can pick its LDS tile halo (3 / 7 / 11 px) on the host and launch
+    exactly one kernel -- offsets of a layer change slowly from step to step, and the choice affects speed only (samples beyond the
+    tile gather from global memory).  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the components exceed
+    3.5 px, 7 px while < 1 % exceed 7.5 px, else 11 px (7 px above 64 output channels)."""
+
+    def __init__(self):
+        self.layers = {}     # id(weight) -> [weakref, pinned host counters, event, n_samples, last decision]
+
+    def record(self, weight, probe_dev, nsamples):
+        import weakref
+        e = self.layers.get(id(weight))
+        if e is None or e[0]() is not weight:
+            e = [weakref.ref(weight), torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0, 0]
+            self.layers[id(weight)] = e
+            for k in [k for k, v in self.layers.items() if v[0]() is None]:
+                del self.layers[k]
+        e[1].copy_(probe_dev, non_blocking=True)
+        e[2].record()
+        e[3] = int(nsamples)
+
+    def forward_halo(self, weight, Co):
+        e = self.layers.get(id(weight))
+        if e is None or e[0]() is not weight or e[3] == 0:
+            return 0
+        if e[2].query():     # the copy has landed: refresh the decision (otherwise keep the previous one)
+            c, n = e[1], e[3]
+            if int(c[1]) * 100 < 8 * n:
+                e[4] = 3
+            elif int(c[3]) * 100 < n or Co > 64:
+                e[4] = 7
+            else:
+                e[4] = 11
+        return e[4]
+
+
+dcn_offset_stats = DcnOffsetStats()
+
+
 class ModulatedDeformConvFunction(Function):
     """Same signature and semantics as the reference's autograd Function
     (codes/models/archs/dcn/deform_conv.py:97-153)."""
@@ -602,8 +642,17 @@ class _DcnPackFused(Function):
         flags = 0x100 if ws is not None else 0
         if ws is None:
             ws = _workspace(nbytes, x.device)
+        # Halo of the forward's LDS tile.  Training: chosen HERE from the offset counters the previous backward of this layer left
+        # (copied to the host asynchronously, see DcnOffsetStats) -- one kernel launch, no probe pass in the forward.  Inference (no
+        # gradient wanted): a probe pass + selection on the device.
+        training = any(ctx.needs_input_grad)
+        probe = None
+        if training:
+            flags |= dcn_offset_stats.forward_halo(weight, Co) << 10
+        elif stride == 1 and dilation == 1:
+            probe = torch.zeros(8, dtype=torch.int32, device=x.device)
         _lib.check(L.rvsr_dcn_pack_forward(_p(x), _p(weight), _p(bias), _p(om), _p(out), B, C, H, W, Co, stride,
-                                           padding, dilation, dg, act | flags, slope, _p(ws), ws.numel(), _stream()),
+                                           padding, dilation, dg, act | flags, slope, _p(probe), _p(ws), ws.numel(), _stream()),
                    'dcn_pack_forward')
         ctx.cfg = (stride, padding, dilation, dg, act, slope, bias is not None)
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
@@ -627,8 +676,15 @@ class _DcnPackFused(Function):
         nbytes = L.rvsr_modulated_deform_conv_backward_workspace_bytes(B, C, H, W, Co, stride, padding, dilation)
         ws = _workspace(nbytes, x.device)
         gslope = 0.0 if act == ACT_RELU else slope
+        # offset counters of this layer: the backward selects its window halo from them on the device, and a copy travels to the host
+        # (no synchronisation) for the forward of the next step
+        probe = None
+        if stride == 1 and dilation == 1 and C % (8 * dg) == 0:
+            probe = torch.zeros(8, dtype=torch.int32, device=x.device)
+            _lib.check(L.rvsr_dcn_offset_probe(_p(om), B, om.shape[2], om.shape[3], dg, _p(probe), _stream()), 'dcn_offset_probe')
+            dcn_offset_stats.record(weight, probe, B * dg * 18 * ((om.shape[2] + 15) // 16) * om.shape[3])
         _lib.check(L.rvsr_dcn_pack_backward(_p(x), _p(weight), _p(om), _p(gout), _p(act_out), gslope, _p(gx), _p(gw),
-                                            _p(gb), _p(gom), B, C, H, W, Co, stride, padding, dilation, dg, _p(ws),
+                                            _p(gb), _p(gom), B, C, H, W, Co, stride, padding, dilation, dg, _p(probe), _p(ws),
                                             ws.numel(), _stream()), 'dcn_pack_backward')
         return (None if dep is not None else gx), gom, gw, gb, None, None, None, None, None, None, None
 
