@@ -794,6 +794,9 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #pragma unroll
         for (int tap = 0; tap < T; ++tap) {
             const int sl = tap & 1;
+#ifdef RVSR_TIMELINE
+            if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[100 + wave * 12 + tap] = __builtin_amdgcn_s_memtime();
+#endif
             if (tap + 1 < T) fetch(tap + 1, sl ^ 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -824,6 +827,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #ifdef RVSR_TIMELINE
         if (blockIdx.x == 77 && lane == 0 && q == Q - 3) rvsr_dbg[70 + wave] = __builtin_amdgcn_s_memtime();
         if (blockIdx.x == 77 && lane == 0 && q == Q - 4) rvsr_dbg[90 + wave] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[100 + wave * 12 + 9] = __builtin_amdgcn_s_memtime();
 #endif
         const int k = k_cur;
         const bool last_chunk = c_cur == nchunks - 1;
@@ -856,6 +860,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         STAMP(3 + (q & 7) * 3);
 #ifdef RVSR_TIMELINE
         if (blockIdx.x == 77 && lane == 0 && q == Q - 4) rvsr_dbg[80 + wave] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[100 + wave * 12 + 10] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 77 && lane == 0 && q == Q - 7) rvsr_dbg[100 + wave * 12 + 11] = __builtin_amdgcn_s_memtime();
 #endif
     }
     STAMP(61);
