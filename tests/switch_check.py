@@ -33,13 +33,14 @@ def main():
         errs.append(rel_err(out.detach().cpu(), oracle_dcn(*[x.detach() for x in ref], 1, 1, 1, 1, 8)))
         print('dcn', C, Co, H, W, ostd, ' '.join('%.1e' % e for e in errs))
         worst = max(worst, max(errs))
-    for k, s, Ci, Co in ((3, 1, 64, 64), (3, 1, 128, 216), (1, 1, 64, 64), (3, 2, 64, 64)):
+    # (the 24 x 128 frame takes the 8 x 64 tile of conv_fwd5 unless RVSR_CONV_WIDE=0, the 36 x 72 ones its 16 x 32 tile)
+    for k, s, Ci, Co, Hc, Wc in ((3, 1, 64, 64, 36, 72), (3, 1, 64, 64, 24, 128), (3, 1, 128, 216, 36, 72), (1, 1, 64, 64, 36, 72), (3, 2, 64, 64, 36, 72)):
         g = torch.Generator().manual_seed(k * 10 + s)
         conv = torch.nn.Conv2d(Ci, Co, k, s, k // 2)
         with torch.no_grad():
             conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (3.0 * Ci ** 0.5))
             conv.bias.copy_(torch.randn(Co, generator=g) * 0.1)
-        x = torch.randn(2, Ci, 36, 72, generator=g)
+        x = torch.randn(2, Ci, Hc, Wc, generator=g)
         wr, xr = conv.weight.detach().double().requires_grad_(True), x.double().requires_grad_(True)
         z = F.conv2d(xr, wr, conv.bias.detach().double(), s, k // 2)
         yr = F.leaky_relu(z, 0.1)
@@ -52,7 +53,7 @@ def main():
         y = RF.conv2d(xg, conv, act=RF.ACT_LRELU, slope=0.1)
         y.backward(gout.float().to(d))
         errs = [rel_err(y.detach().cpu(), yr.detach()), rel_err(xg.grad.cpu(), xr.grad), rel_err(conv.weight.grad.cpu(), wr.grad)]
-        print('conv', k, s, Ci, Co, ' '.join('%.1e' % e for e in errs))
+        print('conv', k, s, Ci, Co, Hc, Wc, ' '.join('%.1e' % e for e in errs))
         worst = max(worst, max(errs))
     torch.cuda.synchronize()
     print('worst rel_err %.3e' % worst)
