@@ -75,3 +75,40 @@ def test_config5_frame_forward_vs_oracle(gemm_mode):
         out = modulated_deform_conv(x.to(d), off.to(d), m.to(d), w.to(d), b.to(d), 1, 1, 1, 1, 8)
     torch.cuda.synchronize()
     check('out', out, oref, 2e-5 if gemm_mode == 'f32' else 1e-4)
+
+
+@pytest.mark.parametrize('ostd,halo', [(0.1, 3), (2.5, 7), (6.0, 11)])   # (std 2.5: 16 % beyond 3.5 px, 0.3 % beyond 7.5 px)
+def test_fused_pack_halo_selection_vs_oracle(ostd, halo, gemm_mode):
+    """The fused pack (functional.dcn_pack, raw conv_offset_mask tensor) picks the forward's LDS tile halo itself: in training from
+    the offset counters the PREVIOUS backward of the layer left on the host (functional.DcnOffsetStats), without gradients from a
+    probe pass on the device.  Both paths against the oracle on a 180 x 320 frame: pass 1 has no statistic yet (3 px tile), pass 2
+    runs the tile the counters ask for, the no-grad call selects on the device; all three must agree with the oracle, and the
+    recorded decision must be the one the offsets imply."""
+    from realvsr_amd import functional as RF
+    B, C, H, W, seed = 1, 64, 180, 320, int(1000 * ostd) + 3
+    x, off, m, w, b, gout = _inputs(B, C, H, W, ostd, seed)
+    logit = torch.log(m.clamp(1e-4, 1 - 1e-4)) - torch.log1p(-m.clamp(1e-4, 1 - 1e-4))
+    om = torch.cat([off, logit], 1)
+    from oracle.dcn_oracle import modulated_deform_conv
+    ref_leaves = [t.clone().requires_grad_(True) for t in (x, om, w, b)]
+    o_, m_ = ref_leaves[1][:, :144], torch.sigmoid(ref_leaves[1][:, 144:])
+    oref = modulated_deform_conv(ref_leaves[0], o_, m_, ref_leaves[2], ref_leaves[3], 1, 1, 1, 1, 8)
+    oref.backward(gout)
+    d = dev()
+    wd = w.to(d).requires_grad_(True)
+    tol = 2e-5 if gemm_mode == 'f32' else 1e-4
+    for it in range(2):
+        leaves = [x.to(d).requires_grad_(True), om.to(d).requires_grad_(True), wd, b.to(d).requires_grad_(True)]
+        wd.grad = None
+        out = RF.dcn_pack(*leaves, 1, 1, 1, 8)
+        out.backward(gout.to(d))
+        torch.cuda.synchronize()
+        check('out pass %d' % it, out, oref.detach(), tol)
+        for name, a, r in zip(('grad_input', 'grad_offset_mask', 'grad_weight', 'grad_bias'), [l.grad for l in leaves], [l.grad for l in ref_leaves]):
+            check('%s pass %d' % (name, it), a, r, 1e-4)
+    if gemm_mode != 'f32':   # (the exact-f32 mode runs the first-generation kernels: no tile halo to choose)
+        assert RF.dcn_offset_stats.forward_halo(wd, C) == halo
+    with torch.no_grad():
+        out = RF.dcn_pack(x.to(d), om.to(d), wd.detach(), b.to(d), 1, 1, 1, 8)
+    torch.cuda.synchronize()
+    check('out no-grad', out, oref.detach(), tol)
