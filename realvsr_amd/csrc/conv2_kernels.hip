@@ -20,8 +20,8 @@
 #include "bf16x3.h"
 
 #ifdef RVSR_TIMELINE
-__device__ unsigned long long rvsr_dbg[256];
-extern "C" int rvsr_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg), sizeof(unsigned long long) * 256); }
+__device__ unsigned long long rvsr_dbg[512];
+extern "C" int rvsr_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg), sizeof(unsigned long long) * 512); }
 #define STAMP(i) do { if (blockIdx.x == 77 && tid == 0) rvsr_dbg[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         for (int tap = 0; tap < T; ++tap) {
             const int sl = tap & 1;
 #ifdef RVSR_TIMELINE
-            if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[100 + wave * 12 + tap] = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[300 + wave * 12 + tap] = __builtin_amdgcn_s_memtime();
 #endif
             if (tap + 1 < T) fetch(tap + 1, sl ^ 1);
 #pragma unroll
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #ifdef RVSR_TIMELINE
         if (blockIdx.x == 77 && lane == 0 && q == Q - 3) rvsr_dbg[70 + wave] = __builtin_amdgcn_s_memtime();
         if (blockIdx.x == 77 && lane == 0 && q == Q - 4) rvsr_dbg[90 + wave] = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[100 + wave * 12 + 9] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[300 + wave * 12 + 9] = __builtin_amdgcn_s_memtime();
 #endif
         const int k = k_cur;
         const bool last_chunk = c_cur == nchunks - 1;
@@ -860,8 +860,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         STAMP(3 + (q & 7) * 3);
 #ifdef RVSR_TIMELINE
         if (blockIdx.x == 77 && lane == 0 && q == Q - 4) rvsr_dbg[80 + wave] = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[100 + wave * 12 + 10] = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 77 && lane == 0 && q == Q - 7) rvsr_dbg[100 + wave * 12 + 11] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[300 + wave * 12 + 10] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 77 && lane == 0 && q == Q - 7) rvsr_dbg[300 + wave * 12 + 11] = __builtin_amdgcn_s_memtime();
 #endif
     }
     STAMP(61);
@@ -1275,17 +1275,20 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     for (int tile = t_begin; tile < t_end; ++tile) {
         const TilePos next_pos = tile_pos(tile + 1 < t_end ? tile + 1 : tile);
         const int ti = tile - t_begin;
-        if (ti < 6) STAMP(100 + ti * 5);
+        if (ti < 6) STAMP(200 + ti * 5);
         commit();
-        if (ti < 6) STAMP(101 + ti * 5);
+        if (ti < 6) STAMP(201 + ti * 5);
         __syncthreads();
-        if (ti < 6) STAMP(102 + ti * 5);
-        if (ti < 6) STAMP(103 + ti * 5);
+        if (ti < 6) STAMP(202 + ti * 5);
+        if (ti < 6) STAMP(203 + ti * 5);
         const bool more = tile + 1 < t_end;
         if (!m_live && more) issue_loads(next_pos, -1);
         if (m_live) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
+#ifdef RVSR_TIMELINE
+                if (blockIdx.x == 77 && blockIdx.z == 0 && lane == 0 && ti == 3) rvsr_dbg[120 + wave * 10 + ks] = __builtin_amdgcn_s_memtime();
+#endif
                 if (GMODE != 2 || more) issue_loads(next_pos, ks);   // (unconditional for the plain view: after the last tile it re-reads that tile)
                 __builtin_amdgcn_sched_barrier(0);
                 const int row = ks >> 1, cb = (ks & 1) * 16 + 8 * hi;  // this lane's 8 pixels: row, cols cb..cb+7
@@ -1303,7 +1306,10 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                 }
             }
         }
-        if (ti < 6) STAMP(104 + ti * 5);
+        if (ti < 6) STAMP(204 + ti * 5);
+#ifdef RVSR_TIMELINE
+        if (blockIdx.x == 77 && blockIdx.z == 0 && lane == 0 && ti == 3) rvsr_dbg[120 + wave * 10 + 8] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
     }
 

@@ -8,7 +8,7 @@ for _ in range(3):
     y = RF.conv2d(x, conv, RF.ACT_LRELU)
 torch.cuda.synchronize()
 L = ctypes.CDLL(os.environ['RVSR_SO'])
-buf = (ctypes.c_ulonglong * 256)()
+buf = (ctypes.c_ulonglong * 512)()
 print('rc', L.rvsr_debug_read(buf))
 t = list(buf)
 names = {0: 'tile start'}
@@ -29,10 +29,10 @@ if V3:
     if V5:
         print('stage Q-3 per wave: loop time after the common barrier release:', [int(t[70 + w] - t[80 + w]) for w in range(8)])
         print('stage Q-4 loop-end skew per wave:', [int(t[90 + w] - min(t[90:98])) for w in range(8)])
-        t0 = min(t[100 + w * 12 + 11] for w in range(8))
+        t0 = min(t[300 + w * 12 + 11] for w in range(8))
         print('stage Q-6, ticks since the first wave left the previous barrier; per wave: barrier passed | start of taps 0..8 | loop end | next barrier passed')
         for w in range(8):
-            r = [int(t[100 + w * 12 + i] - t0) for i in (11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)]
+            r = [int(t[300 + w * 12 + i] - t0) for i in (11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)]
             print('  wave %d:' % w, r, ' per tap:', [r[i + 1] - r[i] for i in range(1, 10)])
     order = sorted(names, key=lambda i: t[i])
     prev = t[order[0]]
