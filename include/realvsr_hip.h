@@ -83,6 +83,31 @@ int rvsr_modulated_deform_conv_backward(const float* input, const float* weight,
                                         int group, int deformable_group, int with_bias,
                                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* 1b. DCNv1 -- the other three functions of the reference's pybind module (deform_conv_cuda.cpp:152-260 deform_conv_forward_cuda,
+ * :262-374 deform_conv_backward_input_cuda, :376-488 deform_conv_backward_parameters_cuda; registration :687-701), same argument order
+ * (kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group[, scale], im2col_step) with the tensors as plain pointers:
+ *   input (B,C,H,W), offset (B, 2*dg*kH*kW, Ho, Wo), weight (Co, C, kH, kW), output / grad_output (B,Co,Ho,Wo); no bias, no mask.
+ * The reference's `columns` / `ones` temporaries do not exist here (no column matrix); `im2col_step` has to divide the batch
+ * (deform_conv.py:41) and is otherwise unused.  Same geometry limits as section 1 (3x3, group 1, isotropic stride / pad / dilation).
+ * backward_input accumulates into the caller-zeroed grad_input and writes grad_offset; backward_parameters accumulates scale * gradient
+ * into the caller-zeroed grad_weight (scale must be 1, what deform_conv.py:76 passes).
+ * workspace: rvsr_deform_conv_workspace_bytes(...) bytes for all three. */
+size_t rvsr_deform_conv_workspace_bytes(int batch, int channels, int height, int width, int channels_out, int kW, int kH, int dW,
+                                        int padW, int dilationW, int deformable_group);
+int rvsr_deform_conv_forward(const float* input, const float* weight, const float* offset, float* output, int batch, int channels,
+                             int height, int width, int channels_out, int kW, int kH, int dW, int dH, int padW, int padH,
+                             int dilationW, int dilationH, int group, int deformable_group, int im2col_step, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int rvsr_deform_conv_backward_input(const float* input, const float* offset, const float* grad_output, float* grad_input,
+                                    float* grad_offset, const float* weight, int batch, int channels, int height, int width,
+                                    int channels_out, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                    int dilationH, int group, int deformable_group, int im2col_step, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+int rvsr_deform_conv_backward_parameters(const float* input, const float* offset, const float* grad_output, float* grad_weight,
+                                         int batch, int channels, int height, int width, int channels_out, int kW, int kH, int dW,
+                                         int dH, int padW, int padH, int dilationW, int dilationH, int group, int deformable_group,
+                                         float scale, int im2col_step, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fused core of ModulatedDeformConvPack.forward (deform_conv.py:274-292): `om` is the raw
  * (B,3*dg*9,Ho,Wo) output of conv_offset_mask; torch.chunk/torch.cat become addressing (channels
  * [0,2*dg*9) are the offsets, the rest mask logits) and torch.sigmoid runs in-kernel.

@@ -143,3 +143,30 @@ class ModulatedDeformConvOracle(torch.autograd.Function):
 
 
 modulated_deform_conv = ModulatedDeformConvOracle.apply
+
+
+def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+    """DCNv1 (deform_conv.py:15-95 -> deform_conv_cuda.cpp:152-488 -> kernel.cu:190-465), TEST INFRASTRUCTURE ONLY.
+
+    The reference's v1 device code is its modulated code with the mask factor deleted, line for line:
+      deformable_im2col_gpu_kernel        kernel.cu:190-241  ==  modulated_deformable_im2col_gpu_kernel        :571-633 without `* mask` (:621)
+      deformable_col2im_gpu_kernel        kernel.cu:279-335  ==  modulated_deformable_col2im_gpu_kernel        :636-693 without `* mask` (:666)
+      deformable_col2im_coord_gpu_kernel  kernel.cu:373-430  ==  modulated_deformable_col2im_coord_gpu_kernel  :696-767 without `* mask` (:751) and
+                                                                 without the grad_mask output
+      helpers :84-188 == :467-568 (same zero-outside bilinear rule, same corner / coordinate weights, same -2 sentinel, same 5x5 window)
+    and its host functions run the same per-sample GEMMs (cpp:209-240, 317-352, 436-470 vs :539-561, 617-671) without a bias; `im2col_step` only
+    batches the column buffer.  The restatement is therefore the modulated oracle on a mask of ones, with the v1 wrapper's own checks
+    (4-D input, im2col_step divides the batch: deform_conv.py:19-21,40-41).  Parity pin: none beyond the modulated oracle's (the reference has no
+    CPU path and no test for this operator) -- identities + finite differences in tests/test_oracle_dcn.py."""
+    from torch.nn.modules.utils import _pair
+    if input is not None and input.dim() != 4:
+        raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    assert sh == sw and ph == pw and dh == dw, 'the C restatement takes isotropic geometry'
+    cur = min(im2col_step, input.shape[0])
+    assert input.shape[0] % cur == 0, 'im2col step must divide batchsize'
+    kh, kw = weight.shape[2:]
+    Ho = (input.shape[2] + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (input.shape[3] + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    mask = torch.ones(input.shape[0], deformable_groups * kh * kw, Ho, Wo, dtype=input.dtype)
+    return ModulatedDeformConvOracle.apply(input, offset, mask, weight, None, sh, ph, dh, groups, deformable_groups)

@@ -11,9 +11,10 @@ checkpoints load with ``strict=True``.  The arithmetic runs in librealvsr_hip.so
   kernel and the DCN consumes its raw 3*dg*9-channel output directly (chunk / cat / sigmoid are
   addressing + an in-kernel sigmoid) -> rvsr_dcn_pack_{forward,backward}.  ``act`` lets the
   caller fuse the LeakyReLU that follows the pack in PCD_Align (EDVR_arch.py:107,130).
-* DCNv1 (``deform_conv`` / ``DeformConv`` / ``DeformConvPack``, deform_conv.py:15-95,156-226):
-  imported by no architecture in the reference; the names exist for API
-  parity and raise NotImplementedError when called -- there is no silent fallback.
+* DCNv1 (``deform_conv`` / ``DeformConv`` / ``DeformConvPack``, deform_conv.py:15-95,156-226): imported by no
+  architecture in the reference; the reference's v1 kernels are its modulated kernels without the
+  mask factor and without a bias (kernel.cu:190-465 vs :571-767), so the operator runs the same HIP kernels on a mask of
+  ones -> rvsr_deform_conv_{forward,backward_input,backward_parameters}.  Same geometry limits as the modulated operator.
 """
 import math
 
@@ -22,15 +23,7 @@ import torch.nn as nn
 from torch.nn.modules.utils import _pair
 
 from ... import functional as RF
-from ...functional import ModulatedDeformConvFunction, modulated_deform_conv
-
-
-def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
-                im2col_step=64):
-    if input is not None and input.dim() != 4:
-        raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
-    raise NotImplementedError('DCNv1 (deform_conv) is outside the MI355X hot path: no architecture of the '
-                              'reference uses it; use modulated_deform_conv')
+from ...functional import DeformConvFunction, ModulatedDeformConvFunction, deform_conv, modulated_deform_conv
 
 
 class DeformConv(nn.Module):
@@ -63,7 +56,12 @@ class DeformConvPack(DeformConv):
         self.conv_offset.bias.data.zero_()
 
     def forward(self, x):
-        return deform_conv(x, None, self.weight, self.stride, self.padding, self.dilation, self.groups,
+        # (deform_conv.py:222-226) conv_offset is an ordinary convolution with the DCN's own kernel size / stride / padding: the fused
+        # conv kernel covers what the HIP deformable kernels cover (3x3, padding 1, isotropic stride)
+        if self.kernel_size != (3, 3) or self.padding != (1, 1) or self.stride[0] != self.stride[1]:
+            raise RuntimeError('DeformConvPack: only 3x3 / padding 1 / isotropic stride is implemented on the HIP path')
+        offset = RF.conv2d(x, self.conv_offset)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
                            self.deformable_groups)
 
 

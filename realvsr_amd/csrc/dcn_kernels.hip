@@ -549,6 +549,85 @@ extern "C" int rvsr_modulated_deform_conv_backward(const float* input, const flo
                              grad_weight, with_bias ? grad_bias : nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- DCNv1 (deform_conv_cuda.cpp:152-488: deform_conv_forward_cuda / deform_conv_backward_input_cuda / deform_conv_backward_parameters_cuda).
+// The reference's v1 kernels (kernel.cu:190-465, helpers :84-188) are its modulated kernels (:571-767, helpers :467-568) without the mask
+// factor and without a bias: same sampling positions, same zero-outside bilinear rule, same 5x5 scatter window and -2 sentinel.  The three
+// entry points therefore run the modulated kernels on a mask of ones kept in the workspace.  `im2col_step` only shapes the reference's column
+// buffer; it is checked (it has to divide the batch, deform_conv.py:41) and otherwise unused -- there is no column buffer here.
+// Workspace: [ones: B*dg*9*Ho*Wo floats][grad_mask scratch: the same][the modulated operator's workspace]. ----
+static size_t dcn1_mask_bytes(int batch, int height, int width, int kh, int kw, int stride, int pad, int dil, int dg) {
+    const int Ho = (height + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    const size_t n = (size_t)batch * dg * kh * kw * (Ho > 0 ? Ho : 0) * (Wo > 0 ? Wo : 0) * sizeof(float);
+    return (n + 255) & ~(size_t)255;
+}
+extern "C" size_t rvsr_deform_conv_workspace_bytes(int batch, int channels, int height, int width, int channels_out, int kW, int kH,
+                                                   int dW, int padW, int dilationW, int deformable_group) {
+    const size_t fw = rvsr_modulated_deform_conv_forward_workspace_bytes(channels, channels_out);
+    const size_t bw = rvsr_modulated_deform_conv_backward_workspace_bytes(batch, channels, height, width, channels_out, dW, padW, dilationW);
+    return 2 * dcn1_mask_bytes(batch, height, width, kH, kW, dW, padW, dilationW, deformable_group) + (fw > bw ? fw : bw);
+}
+static int dcn1_setup(DcnGeom& d, const char* who, const float* input, const float* offset, int batch, int channels, int height, int width,
+                      int channels_out, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW, int dilationH, int group,
+                      int deformable_group, int im2col_step, void* workspace, size_t workspace_bytes, hipStream_t st, float** ones,
+                      float** scratch, void** ws2, size_t* ws2_bytes) {
+    const char* why = "";
+    if (im2col_step <= 0 || batch % im2col_step != 0) FAIL(RVSR_ERR_BAD_ARG, "%s: im2col step must divide batchsize", who);
+    const size_t mb = dcn1_mask_bytes(batch, height, width, kH, kW, dW, padW, dilationW, deformable_group);
+    if (!workspace || workspace_bytes < 2 * mb) FAIL(RVSR_ERR_WORKSPACE, "%s: workspace %zu B < %zu B", who, workspace_bytes, 2 * mb);
+    *ones = (float*)workspace;
+    *scratch = (float*)((char*)workspace + mb);
+    *ws2 = (char*)workspace + 2 * mb;
+    *ws2_bytes = workspace_bytes - 2 * mb;
+    int rc = fill_geom(d, input, offset, 0, *ones, 0, 0, batch, channels, height, width, channels_out, kH, kW, dH, dW, padH, padW, dilationH,
+                       dilationW, group, deformable_group, &why);
+    if (rc) FAIL(rc, "%s: %s", who, why);
+    d.off_bs = (size_t)2 * 9 * deformable_group * d.Ho * d.Wo;
+    d.mask_bs = (size_t)9 * deformable_group * d.Ho * d.Wo;
+    if (hipMemsetD32Async((hipDeviceptr_t)*ones, 0x3f800000, (size_t)batch * d.mask_bs, st) != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "%s: fill", who);
+    return RVSR_OK;
+}
+extern "C" int rvsr_deform_conv_forward(const float* input, const float* weight, const float* offset, float* output, int batch, int channels,
+                                        int height, int width, int channels_out, int kW, int kH, int dW, int dH, int padW, int padH,
+                                        int dilationW, int dilationH, int group, int deformable_group, int im2col_step, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (!weight || !output) FAIL(RVSR_ERR_BAD_ARG, "deform_conv_forward: null weight/output");
+    DcnGeom d; float *ones, *scratch; void* ws2; size_t n2;
+    int rc = dcn1_setup(d, "deform_conv_forward", input, offset, batch, channels, height, width, channels_out, kW, kH, dW, dH, padW, padH, dilationW,
+                        dilationH, group, deformable_group, im2col_step, workspace, workspace_bytes, (hipStream_t)stream, &ones, &scratch, &ws2, &n2);
+    if (rc) return rc;
+    return dcn_forward_impl(d, weight, nullptr, output, 0, 0.f, ws2, n2, (hipStream_t)stream);
+}
+// grad_input is accumulated into (the caller zeroes it, deform_conv.py:62), grad_offset is written
+extern "C" int rvsr_deform_conv_backward_input(const float* input, const float* offset, const float* grad_output, float* grad_input,
+                                               float* grad_offset, const float* weight, int batch, int channels, int height, int width,
+                                               int channels_out, int kW, int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                               int dilationH, int group, int deformable_group, int im2col_step, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+    if (!weight || !grad_output || !grad_input || !grad_offset) FAIL(RVSR_ERR_BAD_ARG, "deform_conv_backward_input: null argument");
+    DcnGeom d; float *ones, *scratch; void* ws2; size_t n2;
+    int rc = dcn1_setup(d, "deform_conv_backward_input", input, offset, batch, channels, height, width, channels_out, kW, kH, dW, dH, padW, padH,
+                        dilationW, dilationH, group, deformable_group, im2col_step, workspace, workspace_bytes, (hipStream_t)stream, &ones, &scratch,
+                        &ws2, &n2);
+    if (rc) return rc;
+    return dcn_backward_impl(d, weight, grad_output, nullptr, 0.f, grad_input, grad_offset, d.off_bs, scratch, d.mask_bs, nullptr, nullptr, ws2, n2,
+                             (hipStream_t)stream);
+}
+// grad_weight is accumulated into (the caller zeroes it, deform_conv.py:71); `scale` multiplies the contribution (the reference passes 1)
+extern "C" int rvsr_deform_conv_backward_parameters(const float* input, const float* offset, const float* grad_output, float* grad_weight,
+                                                    int batch, int channels, int height, int width, int channels_out, int kW, int kH, int dW,
+                                                    int dH, int padW, int padH, int dilationW, int dilationH, int group, int deformable_group,
+                                                    float scale, int im2col_step, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!grad_output || !grad_weight) FAIL(RVSR_ERR_BAD_ARG, "deform_conv_backward_parameters: null argument");
+    if (scale != 1.f) FAIL(RVSR_ERR_UNSUPPORTED, "deform_conv_backward_parameters: scale %g (only 1 is built; deform_conv.py:76 passes 1)", (double)scale);
+    DcnGeom d; float *ones, *scratch; void* ws2; size_t n2;
+    int rc = dcn1_setup(d, "deform_conv_backward_parameters", input, offset, batch, channels, height, width, channels_out, kW, kH, dW, dH, padW, padH,
+                        dilationW, dilationH, group, deformable_group, im2col_step, workspace, workspace_bytes, (hipStream_t)stream, &ones, &scratch,
+                        &ws2, &n2);
+    if (rc) return rc;
+    return dcn_backward_impl(d, nullptr /* the weights: not read by the weight-gradient kernels */, grad_output, nullptr, 0.f, nullptr, nullptr, d.off_bs, nullptr,
+                             d.mask_bs, grad_weight, nullptr, ws2, n2, (hipStream_t)stream);
+}
+
 // ---- fused ModulatedDeformConvPack core (deform_conv.py:274-292): `om` is the raw 3*dg*9-channel output of
 // conv_offset_mask; chunk/cat is pure addressing (channels [0,2*dg*9) = offsets, the rest = mask logits) and the
 // sigmoid runs in-kernel.  Optional LeakyReLU/ReLU epilogue (EDVR_arch.py:107,130). ----

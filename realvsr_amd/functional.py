@@ -619,6 +619,76 @@ class ModulatedDeformConvFunction(Function):
 modulated_deform_conv = ModulatedDeformConvFunction.apply
 
 
+class DeformConvFunction(Function):
+    """DCNv1, same signature and semantics as the reference's autograd Function (codes/models/archs/dcn/deform_conv.py:15-95):
+    (input, offset, weight, stride, padding, dilation, groups, deformable_groups, im2col_step); stride / padding / dilation are
+    ints or pairs.  Runs the modulated kernels on a mask of ones (include/realvsr_hip.h section 1b)."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+        from torch.nn.modules.utils import _pair
+        if input is not None and input.dim() != 4:
+            raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
+        out_size = DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
+        if not input.is_cuda:
+            raise NotImplementedError
+        _need_cuda(input, offset, weight)
+        cur = min(im2col_step, input.shape[0])
+        assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
+        input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()   # deform_conv_cuda.cpp:170-172
+        if offset.shape[0] != input.shape[0]:
+            raise RuntimeError('invalid batch size of offset')                               # deform_conv_cuda.cpp:193
+        ctx.save_for_backward(input, offset, weight)
+        output = input.new_empty(out_size)
+        DeformConvFunction._call('rvsr_deform_conv_forward', ctx, input, weight, cur, [input, weight, offset, output], [])
+        return output
+
+    @staticmethod
+    def _call(name, ctx, input, weight, cur, tensors, extra):
+        L = _lib.lib()
+        B, C, H, W = input.shape
+        Co, _, kh, kw = weight.shape
+        (sh, sw), (ph, pw), (dh, dw) = ctx.stride, ctx.padding, ctx.dilation
+        n = L.rvsr_deform_conv_workspace_bytes(B, C, H, W, Co, kw, kh, sw, pw, dw, ctx.deformable_groups)
+        ws = _workspace(n, input.device)
+        _lib.check(getattr(L, name)(*[_p(t) for t in tensors], B, C, H, W, Co, kw, kh, sw, sh, pw, ph, dw, dh, ctx.groups,
+                                    ctx.deformable_groups, *extra, cur, _p(ws), ws.numel(), _stream()), name[5:])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, weight = ctx.saved_tensors
+        grad_input = grad_offset = grad_weight = None
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        cur = min(ctx.im2col_step, input.shape[0])
+        grad_output = grad_output.contiguous()
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
+            DeformConvFunction._call('rvsr_deform_conv_backward_input', ctx, input, weight, cur,
+                                     [input, offset, grad_output, grad_input, grad_offset, weight], [])
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.zeros_like(weight)
+            DeformConvFunction._call('rvsr_deform_conv_backward_parameters', ctx, input, weight, cur,
+                                     [input, offset, grad_output, grad_weight], [1.0])
+        return grad_input, grad_offset, grad_weight, None, None, None, None, None, None
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        size = (input.size(0), weight.size(0))
+        for d in range(input.dim() - 2):
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            size += ((input.size(d + 2) + 2 * padding[d] - kernel) // stride[d] + 1,)
+        if not all(s > 0 for s in size):
+            raise ValueError('convolution input is too small (output would be {})'.format('x'.join(map(str, size))))
+        return size
+
+
+deform_conv = DeformConvFunction.apply
+
+
 class _DcnPackFused(Function):
     """DCN fed directly by the raw conv_offset_mask output (chunk/cat/sigmoid fused)."""
 

@@ -155,5 +155,5 @@ def test_errors():
     with pytest.raises(RuntimeError):  # non-contiguous input, as deform_conv_cuda.cpp:497
         modulated_deform_conv(torch.randn(1, 8, 8, 16, device=d)[:, :, :, ::2], torch.zeros(1, 18, 8, 8, device=d),
                               torch.ones(1, 9, 8, 8, device=d), torch.randn(8, 8, 3, 3, device=d), None, 1, 1, 1, 1, 1)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):   # (DCNv1 has its own file: tests/test_gpu_dcn_v1.py)
         deform_conv(torch.randn(8, 4, 4), None, None)

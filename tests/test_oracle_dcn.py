@@ -91,3 +91,32 @@ def test_matches_committed_fixture():
     assert rel_err(out, t['out']) < 1e-6
     for leaf, key in zip(leaves, ('gx', 'goffset', 'gmask', 'gweight', 'gbias')):
         assert rel_err(leaf.grad, t[key]) < 2e-6, key
+
+
+# ---- DCNv1 restatement (oracle.dcn_oracle.deform_conv): the modulated oracle on a mask of ones + the v1 wrapper's checks
+def test_v1_zero_offsets_is_conv2d_and_checks():
+    import pytest
+    from oracle.dcn_oracle import deform_conv
+    x, w, _, dg = _rand(seed=7)
+    out = deform_conv(x, torch.zeros(2, dg * 18, 6, 7), w, 1, 1, 1, 1, dg)
+    assert rel_err(out, F.conv2d(x, w, None, padding=1)) < 1e-6
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    out = deform_conv(x, torch.zeros(2, dg * 18, *ref.shape[2:]), w, (2, 2), (1, 1), (1, 1), 1, dg, 1)
+    assert rel_err(out, ref) < 1e-6
+    with pytest.raises(ValueError):
+        deform_conv(x[0], torch.zeros(dg * 18, 6, 7), w)
+    with pytest.raises(AssertionError):
+        deform_conv(torch.cat([x, x[:1]]), torch.zeros(3, dg * 18, 6, 7), w, 1, 1, 1, 1, dg, 2)   # im2col_step 2 does not divide 3
+
+
+def test_v1_f64_finite_differences():
+    from oracle.dcn_oracle import deform_conv
+    g = torch.Generator().manual_seed(8)
+    B, C, Co, dg, H, W = 1, 4, 3, 2, 4, 5
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    off = (torch.rand(B, dg * 18, H, W, generator=g, dtype=torch.float64) * 0.6 + 0.2)
+    off = off * torch.where(torch.rand(off.shape, generator=g) > 0.5, 1.0, -1.0) + torch.randint(-2, 3, off.shape, generator=g).double()
+    off.requires_grad_(True)
+    w = torch.randn(Co, C, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    fn = lambda *a: deform_conv(*a, 1, 1, 1, 1, dg)  # noqa: E731
+    assert torch.autograd.gradcheck(fn, (x, off, w), eps=1e-6, atol=1e-6, rtol=1e-5)
