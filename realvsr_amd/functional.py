@@ -521,31 +521,38 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
 # ------------------------------------------------------------------------------------------ DCN
 class DcnOffsetStats:
     """Per DCN layer: the sampled offset counters of the last backward (components beyond 2.5 .. 11.5 px), brought to the host with a
-    non-blocking copy + event, so that the NEXT forward of the layer can pick its LDS tile halo (3 / 7 / 11 px) on the host and launch
-    exactly one kernel -- offsets of a layer change slowly from step to step, and the choice affects speed only (samples beyond the
-    tile gather from global memory).  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the components exceed
+    non-blocking copy + event, so that the NEXT forward of the layer can pick its LDS tile halo (3 / 7 / 11 px) on the host (after waiting for
+    that copy: the choice is a function of the data, not of host timing) and launch exactly one kernel -- offsets of a layer change slowly
+    from step to step, and the choice affects speed and the last bits of rounding only (samples beyond the tile gather from global
+    memory with the same rules).  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the components exceed
     3.5 px, 7 px while < 1 % exceed 7.5 px, else 11 px (7 px above 64 output channels)."""
 
     def __init__(self):
-        self.layers = {}     # id(weight) -> [weakref, pinned host counters, event, n_samples, last decision]
+        self.layers = {}     # id(weight) -> [weakref, pinned host counters, event, n_samples, last decision, decision is current]
 
     def record(self, weight, probe_dev, nsamples):
         import weakref
         e = self.layers.get(id(weight))
         if e is None or e[0]() is not weight:
-            e = [weakref.ref(weight), torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0, 0]
+            e = [weakref.ref(weight), torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0, 0, True]
             self.layers[id(weight)] = e
             for k in [k for k, v in self.layers.items() if v[0]() is None]:
                 del self.layers[k]
         e[1].copy_(probe_dev, non_blocking=True)
         e[2].record()
         e[3] = int(nsamples)
+        e[5] = False
 
     def forward_halo(self, weight, Co):
         e = self.layers.get(id(weight))
         if e is None or e[0]() is not weight or e[3] == 0:
             return 0
-        if e[2].query():     # the copy has landed: refresh the decision (otherwise keep the previous one)
+        if not e[5]:         # counters not yet turned into a decision
+            # Wait for the copy (issued during the previous backward of this layer).  A query-and-keep-the-old-decision would make the
+            # kernel choice -- and with it the last bits of the forward -- depend on host timing; the host runs ~90 ms ahead of the GPU in
+            # a training loop (tools/cpu_launch_time.py), so this wait only ever holds it back to one step of lead.
+            e[2].synchronize()
+            e[5] = True
             c, n = e[1], e[3]
             if int(c[1]) * 100 < 8 * n:
                 e[4] = 3
