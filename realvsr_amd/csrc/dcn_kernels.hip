@@ -651,7 +651,7 @@ extern "C" int rvsr_dcn_pack_forward(const float* input, const float* weight, co
 }
 
 // The sampled offset statistic on its own (8 zeroed uint32 on the device, 6 used): lets a caller keep the counters, e.g. to choose the
-// forward's halo of the NEXT step on the host without a synchronisation (realvsr_amd.functional), and hand them to the backward.
+// forward's halo of the NEXT step on the host without stalling the GPU (realvsr_amd.functional), and hand them to the backward.
 extern "C" int rvsr_dcn_offset_probe(const float* om, int batch, int height_out, int width_out, int deformable_group, void* probe, void* stream) {
     if (!om || !probe || batch <= 0 || deformable_group <= 0) FAIL(RVSR_ERR_BAD_ARG, "dcn_offset_probe: null/empty argument");
     DcnGeom d;

@@ -754,7 +754,7 @@ class _DcnPackFused(Function):
         ws = _workspace(nbytes, x.device)
         gslope = 0.0 if act == ACT_RELU else slope
         # offset counters of this layer: the backward selects its window halo from them on the device, and a copy travels to the host
-        # (no synchronisation) for the forward of the next step
+        # (asynchronously; the next forward of this layer waits for it) for the forward of the next step
         probe = None
         if stride == 1 and dilation == 1 and C % (8 * dg) == 0:
             probe = torch.zeros(8, dtype=torch.int32, device=x.device)
