@@ -125,8 +125,14 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
             om = RF.conv2d(feat, self.conv_offset_mask)
             return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                self.deformable_groups, act, slope, sink)
+        if self.kernel_size == (3, 3) and self.padding == 1 and self.dilation == 1 and act == RF.ACT_NONE and sink is None:
+            # groups > 1 (deform_conv.py:284-292 as written): the unfused wiring on the composed operator
+            out = RF.conv2d(feat, self.conv_offset_mask)
+            o1, o2, mask = torch.chunk(out, 3, dim=1)
+            return modulated_deform_conv(x, torch.cat((o1, o2), dim=1), torch.sigmoid(mask), self.weight, self.bias, self.stride,
+                                         self.padding, self.dilation, self.groups, self.deformable_groups)
         # Everything the reference's architectures instantiate (EDVR_arch.py:73-74, TDAN_arch.py:29-41) is 3x3, groups=1,
-        # "same" padding.  Other geometries have no HIP kernel here and there is deliberately no library fallback.
-        raise RuntimeError('ModulatedDeformConvPack: only 3x3 / groups=1 / padding=dilation is implemented on the '
+        # "same" padding.  Other kernel sizes have no HIP kernel here and there is deliberately no library fallback.
+        raise RuntimeError('ModulatedDeformConvPack: only 3x3 / padding=dilation is implemented on the '
                            'MI355X path (got kernel %s, groups %d, padding %s, dilation %s)'
                            % (self.kernel_size, self.groups, self.padding, self.dilation))

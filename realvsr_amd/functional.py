@@ -623,7 +623,33 @@ class ModulatedDeformConvFunction(Function):
         return grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None, None
 
 
-modulated_deform_conv = ModulatedDeformConvFunction.apply
+def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """The reference's functional entry point (deform_conv.py:99-100 binds it to ModulatedDeformConvFunction.apply).  groups > 1
+    (deform_conv_cuda.cpp:539-561: one im2col over all channels, then one GEMM per group on that group's slice of the columns) is
+    composed from `groups` calls of the groups == 1 operator on channel slices -- possible whenever a group's channels see whole
+    deformable groups (deformable_groups % groups == 0) or lie inside one (groups % deformable_groups == 0)."""
+    if groups == 1:
+        return ModulatedDeformConvFunction.apply(input, offset, mask, weight, bias, stride, padding, dilation, 1, deformable_groups)
+    if not input.is_cuda:
+        raise NotImplementedError
+    C, Co, dg = input.shape[1], weight.shape[0], deformable_groups
+    K = weight.shape[2] * weight.shape[3]
+    if C % groups or Co % groups or weight.shape[1] * groups != C:
+        raise RuntimeError('modulated_deform_conv: channels (%d -> %d) not divisible into %d groups' % (C, Co, groups))
+    if dg % groups and groups % dg:
+        raise RuntimeError('modulated_deform_conv: groups %d / deformable_groups %d: a group would see part of a deformable group; '
+                           'not implemented on the HIP path' % (groups, dg))
+    cg, og = C // groups, Co // groups
+    outs = []
+    for g in range(groups):
+        if dg % groups == 0:
+            d0, dn = g * (dg // groups), dg // groups
+        else:
+            d0, dn = g // (groups // dg), 1
+        outs.append(ModulatedDeformConvFunction.apply(
+            input[:, g * cg:(g + 1) * cg].contiguous(), offset[:, 2 * K * d0:2 * K * (d0 + dn)], mask[:, K * d0:K * (d0 + dn)],
+            weight[g * og:(g + 1) * og].contiguous(), None if bias is None else bias[g * og:(g + 1) * og], stride, padding, dilation, 1, dn))
+    return torch.cat(outs, 1)
 
 
 class DeformConvFunction(Function):

@@ -157,3 +157,35 @@ def test_errors():
                               torch.ones(1, 9, 8, 8, device=d), torch.randn(8, 8, 3, 3, device=d), None, 1, 1, 1, 1, 1)
     with pytest.raises(ValueError):   # (DCNv1 has its own file: tests/test_gpu_dcn_v1.py)
         deform_conv(torch.randn(8, 4, 4), None, None)
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 48, 4, 2), (1, 32, 32, 1, 2), (1, 64, 32, 2, 4)], ids=lambda c: 'B%d-C%d-Co%d-dg%d-G%d' % c)
+def test_groups_vs_oracle(cfg, gemm_mode):
+    """groups > 1 (deform_conv_cuda.cpp:539-561 per-group GEMMs): composed from groups == 1 calls on channel slices."""
+    from oracle.dcn_oracle import modulated_deform_conv as oracle_dcn
+    from realvsr_amd.archs.dcn import modulated_deform_conv, ModulatedDeformConvPack
+    B, C, Co, dg, G = cfg
+    g = torch.Generator().manual_seed(C + Co + dg + G)
+    H, W = 10, 36
+    t = [torch.randn(B, C, H, W, generator=g), torch.randn(B, dg * 18, H, W, generator=g) * 1.5, torch.rand(B, dg * 9, H, W, generator=g),
+         torch.randn(Co, C // G, 3, 3, generator=g) / (3 * (C // G) ** 0.5), torch.randn(Co, generator=g)]
+    gout = torch.randn(B, Co, H, W, generator=g)
+    ref = [x.clone().requires_grad_(True) for x in t]
+    oref = oracle_dcn(*ref, 1, 1, 1, G, dg)
+    oref.backward(gout)
+    d = dev()
+    got = [x.to(d).requires_grad_(True) for x in t]
+    out = modulated_deform_conv(*got, 1, 1, 1, G, dg)
+    out.backward(gout.to(d))
+    torch.cuda.synchronize()
+    check('out', out, oref.detach(), 2e-5 if gemm_mode == 'f32' else 1e-4)
+    for name, a, r in zip(('grad_input', 'grad_offset', 'grad_mask', 'grad_weight', 'grad_bias'), got, ref):
+        check(name, a.grad, r.grad, 1e-4)
+    # the Pack module with groups > 1: unfused wiring on the composed operator; at init (zero conv_offset_mask) = 0.5 * grouped conv + bias
+    import torch.nn.functional as F
+    pack = ModulatedDeformConvPack(C, Co, 3, stride=1, padding=1, dilation=1, groups=G, deformable_groups=dg).to(d)
+    with torch.no_grad():
+        pack.bias.copy_(t[4])
+    x = t[0].to(d)
+    want = 0.5 * F.conv2d(t[0].double(), pack.weight.detach().double().cpu(), None, padding=1, groups=G) + t[4].double().view(1, -1, 1, 1)
+    check('pack at init', pack(x), want, 2e-5 if gemm_mode == 'f32' else 1e-4)
