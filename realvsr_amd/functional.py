@@ -520,47 +520,53 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
 
 # ------------------------------------------------------------------------------------------ DCN
 class DcnOffsetStats:
-    """Per DCN layer: the sampled offset counters of the last backward (components beyond 2.5 .. 11.5 px), brought to the host with a
-    non-blocking copy + event, so that the NEXT forward of the layer can pick its LDS tile halo (3 / 7 / 11 px) on the host (after waiting for
-    that copy: the choice is a function of the data, not of host timing) and launch exactly one kernel -- offsets of a layer change slowly
-    from step to step, and the choice affects speed and the last bits of rounding only (samples beyond the tile gather from global
-    memory with the same rules).  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the components exceed
-    3.5 px, 7 px while < 1 % exceed 7.5 px, else 11 px (7 px above 64 output channels)."""
+    """Per DCN layer: the sampled offset counters of its last backwards (components beyond 2.5 .. 11.5 px), brought to the host with a
+    non-blocking copy + event, so that a later forward of the layer can pick its LDS tile halo (3 / 7 / 11 px) on the host and launch
+    exactly one kernel.  The forward uses the counters of the backward LAG = 3 calls back and waits for that copy: the choice is a
+    function of the data, never of host timing (a query-and-keep-the-old-decision would make the kernel choice, and with it the last
+    bits of the forward, depend on how far the host happens to run ahead), and a host that is up to three steps ahead of the GPU --
+    which is what absorbs an 80 ms pause of Python's garbage collector, tools/cpu_launch_time.py -- never blocks on it.  Offsets of a
+    layer change slowly from step to step, and the choice affects speed and the last bits of rounding only (samples beyond the tile
+    gather from global memory with the same rules).  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the
+    components exceed 3.5 px, 7 px while < 1 % exceed 7.5 px, else 11 px (7 px above 64 output channels)."""
+    LAG = 3
 
     def __init__(self):
-        self.layers = {}     # id(weight) -> [weakref, pinned host counters, event, n_samples, last decision, decision is current]
+        self.layers = {}     # id(weight) -> [weakref, ring of (pinned host counters, event, n_samples), records so far, decisions by record]
 
     def record(self, weight, probe_dev, nsamples):
         import weakref
         e = self.layers.get(id(weight))
         if e is None or e[0]() is not weight:
-            e = [weakref.ref(weight), torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0, 0, True]
+            ring = [[torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0] for _ in range(self.LAG)]
+            e = [weakref.ref(weight), ring, 0, {}]
             self.layers[id(weight)] = e
             for k in [k for k, v in self.layers.items() if v[0]() is None]:
                 del self.layers[k]
-        e[1].copy_(probe_dev, non_blocking=True)
-        e[2].record()
-        e[3] = int(nsamples)
-        e[5] = False
+        slot = e[1][e[2] % self.LAG]
+        slot[0].copy_(probe_dev, non_blocking=True)
+        slot[1].record()
+        slot[2] = int(nsamples)
+        e[2] += 1
 
     def forward_halo(self, weight, Co):
         e = self.layers.get(id(weight))
-        if e is None or e[0]() is not weight or e[3] == 0:
+        if e is None or e[0]() is not weight or e[2] == 0:
             return 0
-        if not e[5]:         # counters not yet turned into a decision
-            # Wait for the copy (issued during the previous backward of this layer).  A query-and-keep-the-old-decision would make the
-            # kernel choice -- and with it the last bits of the forward -- depend on host timing; the host runs ~90 ms ahead of the GPU in
-            # a training loop (tools/cpu_launch_time.py), so this wait only ever holds it back to one step of lead.
-            e[2].synchronize()
-            e[5] = True
-            c, n = e[1], e[3]
-            if int(c[1]) * 100 < 8 * n:
-                e[4] = 3
+        rec = max(e[2] - self.LAG, 0)            # the record this forward decides from (the oldest one in the ring; the first while it fills)
+        if rec not in e[3]:
+            c, ev, n = e[1][rec % self.LAG]
+            ev.synchronize()
+            if n == 0:
+                halo = 0
+            elif int(c[1]) * 100 < 8 * n:
+                halo = 3
             elif int(c[3]) * 100 < n or Co > 64:
-                e[4] = 7
+                halo = 7
             else:
-                e[4] = 11
-        return e[4]
+                halo = 11
+            e[3] = {rec: halo}
+        return e[3][rec]
 
 
 dcn_offset_stats = DcnOffsetStats()
