@@ -88,21 +88,34 @@ __device__ __forceinline__ void conv2_epilogue_v4(f32x16 (&acc)[MT][2], const Co
     const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
     const int j = lo & 3, col4 = x0 + (lo & ~3);  // this lane's channel-in-group and first pixel column after the transpose
     const bool col_ok = col4 < p.Wout;            // Wout % 4 == 0: the float4 is entirely inside or outside
-    const size_t HW = (size_t)p.Hout * p.Wout;
+    // Raw buffer addressing (p.vec4 implies one batch element of the output spans < 2 GB, rvsr_launch_conv_fwd2): a 32-bit lane offset
+    // (channel within the group, pixel) computed once per row + the channel group's byte offset (one add); a lane without an
+    // element gets an offset beyond the view (its load returns 0, its store is dropped).  The pointer form cost ~13 vector
+    // instructions per store incl. a quarter-rate 32-bit multiply and 64-bit adds: a quarter of the epilogue's issue time.
+    // The group offset is added on the vector side ON PURPOSE: passed as the store's SGPR soffset, which the next store's s_add then
+    // rewrites a few instructions later, the second wave of every SIMD wrote some float4s of its rows to the wrong channel group
+    // (measured: wrong x components in lanes 12-15 / 28-31 of waves 4-7, varying from run to run; loads with a changing soffset are
+    // fine everywhere in this library) -- a store appears to read its soffset later than the SALU may overwrite it.
+    const unsigned HW = (unsigned)(p.Hout * p.Wout), HW4 = 4u * HW;
+    const __amdgpu_buffer_rsrc_t out_rs = buf_view_2g(p.out1 + (size_t)b * p.Co * HW);
+    const __amdgpu_buffer_rsrc_t res_rs = buf_view_2g(MODE == 1 ? p.res + (size_t)b * p.Co * HW : p.out1);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int row = row0 + n;
         if (row >= p.Hout) continue;  // wave-uniform
-        const size_t pix = (size_t)row * p.Wout + col4;
+        const unsigned lane_off = 4u * ((unsigned)(4 * hi + j) * HW + (unsigned)row * p.Wout + col4);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float4 resv[4];
-            if (MODE == 1) {
+            unsigned off[4];
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int o = o0 + m * 32 + 8 * rg + 4 * hi + j;
-                    const bool ok = col_ok && o < p.Co;
-                    resv[rg] = *reinterpret_cast<const float4*>(p.res + (ok ? ((size_t)b * p.Co + o) * HW + pix : 0));
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ob = o0 + m * 32 + 8 * rg;   // (uniform) first channel of the group of 8
+                off[rg] = col_ok && ob + 4 * hi + j < p.Co ? lane_off : 0x80000000u;
+                if (MODE == 1) {
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const f32x4v q = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (int)(off[rg] + (unsigned)ob * HW4), 0, 0));
+                    resv[rg] = make_float4(q.x, q.y, q.z, q.w);
                 }
             }
 #pragma unroll
@@ -110,13 +123,12 @@ __device__ __forceinline__ void conv2_epilogue_v4(f32x16 (&acc)[MT][2], const Co
                 float r0 = acc[m][n][4 * rg + 0], r1 = acc[m][n][4 * rg + 1], r2 = acc[m][n][4 * rg + 2], r3 = acc[m][n][4 * rg + 3];
                 quad_transpose4(r0, r1, r2, r3, lo);
                 const int ol = m * 32 + 8 * rg + 4 * hi + j;
-                const int o = o0 + ol;
                 const float bb = bias_s[ol];
                 float4 v = make_float4(r0 + bb, r1 + bb, r2 + bb, r3 + bb);
                 v.x = v.x > 0.f ? v.x : v.x * neg; v.y = v.y > 0.f ? v.y : v.y * neg;
                 v.z = v.z > 0.f ? v.z : v.z * neg; v.w = v.w > 0.f ? v.w : v.w * neg;
                 if (MODE == 1) { v.x += resv[rg].x; v.y += resv[rg].y; v.z += resv[rg].z; v.w += resv[rg].w; }
-                if (col_ok && o < p.Co) *reinterpret_cast<float4*>(p.out1 + ((size_t)b * p.Co + o) * HW + pix) = v;
+                buf_store4(out_rs, off[rg] + (unsigned)(o0 + m * 32 + 8 * rg) * HW4, 0u, v);
             }
         }
     }
@@ -143,19 +155,26 @@ __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const 
     const int src4 = 4 * (4 * Gn + jn);                       // byte index of the source lane
     const int col4 = x0 + 4 * Gn;
     const bool col_ok = col4 < p.Wout;                        // Wout % 4 == 0
-    const size_t HW = (size_t)p.Hout * p.Wout, pix = (size_t)row * p.Wout + col4;
+    // raw buffer addressing as in conv2_epilogue_v4: a 32-bit lane offset computed once per row + the channel group's offset, added on the vector side
+    const unsigned HW = (unsigned)(p.Hout * p.Wout), HW4 = 4u * HW;
+    const __amdgpu_buffer_rsrc_t out_rs = buf_view_2g(p.out1 + (size_t)b * p.Co * HW);
+    const __amdgpu_buffer_rsrc_t res_rs = buf_view_2g(MODE == 1 ? p.res + (size_t)b * p.Co * HW : p.out1);
+    const unsigned lane_off = 4u * ((unsigned)jn * HW + (unsigned)row * p.Wout + col4);
     const int j = lo & 3;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             float4 resv[2];
-            if (MODE == 1) {
+            unsigned off[2];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int o = o0 + m * 32 + 8 * rg + 4 * s + jn;
-                    const bool ok = col_ok && o < p.Co;
-                    resv[s] = *reinterpret_cast<const float4*>(p.res + (ok ? ((size_t)b * p.Co + o) * HW + pix : 0));
+            for (int s = 0; s < 2; ++s) {
+                const int ob = o0 + m * 32 + 8 * rg + 4 * s;   // (uniform) first of the instruction's 4 channels
+                off[s] = col_ok && ob + jn < p.Co ? lane_off : 0x80000000u;
+                if (MODE == 1) {
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const f32x4v q = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (int)(off[s] + (unsigned)ob * HW4), 0, 0));
+                    resv[s] = make_float4(q.x, q.y, q.z, q.w);
                 }
             }
             float r[2][4];
@@ -179,10 +198,9 @@ __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const 
                     r[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, r[s][e])));
 #pragma unroll
             for (int s = 0; s < 2; ++s) {   // set s: lanes 16 c .. 16 c + 15 = channel 8 rg + 4 s + c, the 64 pixels of the row
-                const int o = o0 + m * 32 + 8 * rg + 4 * s + jn;
                 float4 v = make_float4(r[s][0], r[s][1], r[s][2], r[s][3]);
                 if (MODE == 1) { v.x += resv[s].x; v.y += resv[s].y; v.z += resv[s].z; v.w += resv[s].w; }
-                if (col_ok && o < p.Co) *reinterpret_cast<float4*>(p.out1 + ((size_t)b * p.Co + o) * HW + pix) = v;
+                buf_store4(out_rs, off[s] + (unsigned)(o0 + m * 32 + 8 * rg + 4 * s) * HW4, 0u, v);
             }
         }
     }
@@ -1222,7 +1240,9 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
                            Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode);
     p.wpack = workspace;
     p.swz = rvsr_swizzle_enabled();
-    p.vec4 = (p.Wout % 4 == 0) && ((((uintptr_t)p.out1) | ((uintptr_t)p.res)) & 15) == 0 && !p.ps && p.out2 == nullptr;
+    // (the 16-byte-store epilogues address one batch element of the output / residual with 32-bit byte offsets in a 2 GB buffer view)
+    p.vec4 = (p.Wout % 4 == 0) && ((((uintptr_t)p.out1) | ((uintptr_t)p.res)) & 15) == 0 && !p.ps && p.out2 == nullptr &&
+             sizeof(float) * (size_t)p.Co * p.Hout * p.Wout < ((size_t)1 << 31);
 #define DISPATCH2(KS, S, CCG)                                   \
     do {                                                        \
         if (mt == 1) return launch_fwd2<KS, S, 1, CCG>(p, st);  \

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
                 float4 v = make_float4(r0 + bb, r1 + bb, r2 + bb, r3 + bb);
                 v.x = v.x > 0.f ? v.x : v.x * neg; v.y = v.y > 0.f ? v.y : v.y * neg;
                 v.z = v.z > 0.f ? v.z : v.z * neg; v.w = v.w > 0.f ? v.w : v.w * neg;
-                if (col_ok && o < d.Co) buf_store4(out_rs, lane_off, 4u * (unsigned)(mb * MP + mt * 32 + 8 * rg) * (unsigned)hw, v);
+                // (channel-group offset added on the vector side, not passed as the store's SGPR soffset: conv2_epilogue_v4 has the reason)
+                if (col_ok && o < d.Co) buf_store4(out_rs, lane_off + 4u * (unsigned)(mb * MP + mt * 32 + 8 * rg) * (unsigned)hw, 0u, v);
             }
         }
     } else {
