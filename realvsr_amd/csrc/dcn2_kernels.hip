@@ -1015,7 +1015,9 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
     if (rvsr_g_gemm_mode == 0) {  // bf16x3
         const size_t lds3 = (size_t)16 * 2 * TR * TC + (size_t)2 * (64 + 96) * 272;
         static const int gen = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 4; }();  // developer A/B switch
-        if (gen >= 4 && d.stride == 1 && d.dil == 1 && g.mode == 0 && (d.Wo & 3) == 0 && p.gvec) {
+        // (dcn_bwdw4 addresses 64 gOut planes, 27 offset / mask planes and 8 x planes with 32-bit byte offsets inside 2 GB buffer views)
+        const bool spans_ok = (size_t)256 * d.Ho * d.Wo < ((size_t)1 << 31) && (size_t)32 * d.H * d.W < ((size_t)1 << 31);
+        if (gen >= 4 && d.stride == 1 && d.dil == 1 && g.mode == 0 && (d.Wo & 3) == 0 && p.gvec && spans_ok) {
             if (set_lds(dcn_bwdw4_kernel, lds3)) return -2;
             hipLaunchKernelGGL(dcn_bwdw4_kernel, dim3(P, gy, gz), dim3(512), lds3, st, p);
             return 8 * P;
