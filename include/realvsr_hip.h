@@ -153,7 +153,10 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
  *           w_mode | 2: `workspace` already holds the packed image of these weights (section 2b), the per-call pack is skipped.
  *   out1 (B,Co1,Hout,Wout) [+ out2 (B,Co2,Hout,Wout): rows split, for the gradient of a cat].
  *   residual (NULL or shaped like out1, out2 must be NULL): added after the activation.
- *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope); 3 (with `residual`, ksize 3, stride 1, one output): out = (conv + bias) * (residual > 0 ? 1 : slope),
+ *        i.e. a data gradient multiplied by the derivative of the activation whose saved OUTPUT `residual` is -- the consumers of that
+ *        gradient then need no mask.  Built for the 8 x 64-tile kernel only: returns RVSR_ERR_UNSUPPORTED (without an error message) for
+ *        frames that kernel does not take, and the caller applies the mask on the consumer side (xact / gout_act) instead.
  *   pixel_shuffle 1: out1 is (B,Co/4,2*Hout,2*Wout), written through PixelShuffle(2).
  *   stride 2 only with ksize 3 and in_mode 0.
  *   workspace: rvsr_conv2d_forward_workspace_bytes(C1, C2, Co1+Co2, ksize) bytes (holds the weights

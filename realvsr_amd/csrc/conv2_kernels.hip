@@ -146,7 +146,7 @@ template <int MT, int MODE>
 __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const ConvFwdParams& p, const float* bias_s, int b,
                                                     int o0, int row, int x0, int lo, int hi) {
     if (row >= p.Hout) return;   // wave-uniform
-    const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
+    const float neg = (p.act == 0 || MODE == 4) ? 1.f : (p.act == 1 ? 0.f : p.slope);
     // After transpose + half swap lane 4 G + j holds channel j, pixel quad G = 8 hi + (lo >> 2) of the row.  The store path wants
     // CONSECUTIVE lanes on consecutive addresses (store_micro.hip: 4 x 256 B per instruction = 26 B/clk with lanes 16 c .. 16 c + 15
     // on channel c, 15 B/clk with the channels interleaved lane by lane): one ds_bpermute per register moves the value of lane
@@ -158,7 +158,7 @@ __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const 
     // raw buffer addressing as in conv2_epilogue_v4: a 32-bit lane offset computed once per row + the channel group's offset, added on the vector side
     const unsigned HW = (unsigned)(p.Hout * p.Wout), HW4 = 4u * HW;
     const __amdgpu_buffer_rsrc_t out_rs = buf_view_2g(p.out1 + (size_t)b * p.Co * HW);
-    const __amdgpu_buffer_rsrc_t res_rs = buf_view_2g(MODE == 1 ? p.res + (size_t)b * p.Co * HW : p.out1);
+    const __amdgpu_buffer_rsrc_t res_rs = buf_view_2g(MODE == 1 || MODE == 4 ? p.res + (size_t)b * p.Co * HW : p.out1);
     const unsigned lane_off = 4u * ((unsigned)jn * HW + (unsigned)row * p.Wout + col4);
     const int j = lo & 3;
 #pragma unroll
@@ -171,7 +171,7 @@ __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const 
             for (int s = 0; s < 2; ++s) {
                 const int ob = o0 + m * 32 + 8 * rg + 4 * s;   // (uniform) first of the instruction's 4 channels
                 off[s] = col_ok && ob + jn < p.Co ? lane_off : 0x80000000u;
-                if (MODE == 1) {
+                if (MODE == 1 || MODE == 4) {
                     typedef float f32x4v __attribute__((ext_vector_type(4)));
                     const f32x4v q = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (int)(off[s] + (unsigned)ob * HW4), 0, 0));
                     resv[s] = make_float4(q.x, q.y, q.z, q.w);
@@ -200,6 +200,10 @@ __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const 
             for (int s = 0; s < 2; ++s) {   // set s: lanes 16 c .. 16 c + 15 = channel 8 rg + 4 s + c, the 64 pixels of the row
                 float4 v = make_float4(r[s][0], r[s][1], r[s][2], r[s][3]);
                 if (MODE == 1) { v.x += resv[s].x; v.y += resv[s].y; v.z += resv[s].z; v.w += resv[s].w; }
+                if (MODE == 4) {   // gradient mask: the derivative of the activation whose output `res` is (p.act == 3, neg == 1 above)
+                    v.x *= resv[s].x > 0.f ? 1.f : p.slope; v.y *= resv[s].y > 0.f ? 1.f : p.slope;
+                    v.z *= resv[s].z > 0.f ? 1.f : p.slope; v.w *= resv[s].w > 0.f ? 1.f : p.slope;
+                }
                 buf_store4(out_rs, off[s] + (unsigned)(o0 + m * 32 + 8 * rg + 4 * s) * HW4, 0u, v);
             }
         }
@@ -855,7 +859,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             const Tile cur = tile_of(k);
             const float* bias_s = bias_base + (k & 3) * MP;
             if (WIDE) {   // (launch_fwd5: 16-byte stores, no pixel shuffle, one output tensor)
-                if (p.res != nullptr) conv2_epilogue_wide<MT, 1>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave, cur.x0, lo, hi);
+                if (p.act == 3) conv2_epilogue_wide<MT, 4>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave, cur.x0, lo, hi);
+                else if (p.res != nullptr) conv2_epilogue_wide<MT, 1>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave, cur.x0, lo, hi);
                 else conv2_epilogue_wide<MT, 0>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave, cur.x0, lo, hi);
             } else if (p.ps)
                 conv2_epilogue<MT, 3>(acc, p, bias_s, cur.b, cur.mb * MP, cur.y0 + wave * 2, cur.x0 + lo, hi);
@@ -1191,16 +1196,18 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
     // tile shape: 8 x 64 (256-byte output runs, 16-byte stores, plain vector-staged view) when it wastes no more pixels than 16 x 32
     int th = 16, tw = 32;
     size_t lds_k = lds;
+    if (MT != 2 && p.act == 3) return RVSR_ERR_UNSUPPORTED;   // (mask epilogue: 8 x 64 tile, 64-row m-blocks only)
     if constexpr (MT == 2) {
         static const int wide_ok = [] { const char* e = getenv("RVSR_CONV_WIDE"); return e ? atoi(e) : 1; }();   // developer A/B switch
         const long px_n = (long)((p.Hout + 15) / 16 * 16) * ((p.Wout + 31) / 32 * 32), px_w = (long)((p.Hout + 7) / 8 * 8) * ((p.Wout + 63) / 64 * 64);
+        if (p.act == 3 && !(wide_ok && vec == 1 && p.vec4 && px_w <= px_n)) return RVSR_ERR_UNSUPPORTED;   // (mask epilogue: 8 x 64 tile only)
         if (wide_ok && vec == 1 && p.vec4 && px_w <= px_n) {
             k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true> : conv_fwd5_kernel<MT, false, 1, true>;
             th = 8; tw = 64;
             constexpr int NXW = 2 * 10 * 66;
             lds_k = (size_t)16 * (2 * 2 * NXW + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32 + 16;
             static const int one_wave = [] { const char* e = getenv("RVSR_CONV_FWD6"); return e ? atoi(e) : 0; }();   // developer A/B switch
-            if (one_wave) {   // four waves per workgroup, one per SIMD (conv_fwd6_kernel)
+            if (one_wave && p.act != 3) {   // four waves per workgroup, one per SIMD (conv_fwd6_kernel)
                 auto k6 = va.act != nullptr ? conv_fwd6_kernel<true> : conv_fwd6_kernel<false>;
                 if (set_lds(k6, lds_k)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd6: cannot reserve %zu B of LDS", lds_k);
                 const long items6 = (long)((p.Wout + 63) / 64) * ((p.Hout + 7) / 8) * ((p.Co + 63) / 64) * p.B;

@@ -342,6 +342,13 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
     p.ntx = (Wout + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     p.wpack = nullptr;
+    if (act == 3) {
+        // out = (conv + bias) * (residual > 0 ? 1 : slope): the data gradient of a layer whose INPUT was an activation output, with that
+        // activation's derivative applied on the way out (`residual` = the saved activation output).  Only the 8 x 64-tile kernel has this
+        // epilogue; everything else answers "unsupported" and the caller applies the mask on the consumer side as before.
+        if (!residual || ksize != 3 || stride != 1 || pixel_shuffle || out2 || rvsr_g_gemm_mode != 0) return RVSR_ERR_UNSUPPORTED;
+        return rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
+    }
     if (rvsr_conv_fwd_thin_ok(p, ksize, stride)) return rvsr_launch_conv_fwd_thin(p, st);   // <= 4 output channels: vector ALU, exact f32
     if (rvsr_g_gemm_mode == 0 && (in_mode != 1 || ksize == 3) && (x2 == nullptr || C1 % 8 == 0)) {
         const int rc2 = rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);

@@ -17,6 +17,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_MASK = 3   # rvsr_conv2d_forward only: out = conv * act'(residual) (include/realvsr_hip.h); internal to the fused backward nodes
 
 
 def _p(t):
@@ -94,6 +95,7 @@ class GradSink:
 
 
 _ADOPT_FLAT_GRADS = os.environ.get('RVSR_FLAT_GRAD_ADOPT', '1') != '0'   # developer A/B switch
+_FUSE_GRAD_MASK = os.environ.get('RVSR_FUSE_GRAD_MASK', '1') != '0'     # developer A/B switch (ResBlock backward: relu' in dgrad2's epilogue)
 
 
 def _pgrad(p, zero=False):
@@ -263,8 +265,12 @@ def _conv_fwd(L, x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias
         ws, w_mode = buf, w_mode | 2
     else:
         ws = _workspace(nbytes, torch.device('cuda', torch.cuda.current_device()))
-    _lib.check(L.rvsr_conv2d_forward(x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias, residual, out1, Co1, out2, Co2, B, k,
-                                     stride, w_mode, act, slope, ps, Hout, Wout, _p(ws), ws.numel(), _stream()), what)
+    rc = L.rvsr_conv2d_forward(x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias, residual, out1, Co1, out2, Co2, B, k,
+                               stride, w_mode, act, slope, ps, Hout, Wout, _p(ws), ws.numel(), _stream())
+    if rc == 1 and act == ACT_MASK:     # RVSR_ERR_UNSUPPORTED: the fused gradient mask is an option of one kernel, the caller has a plan B
+        return False
+    _lib.check(rc, what)
+    return True
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -385,20 +391,25 @@ class _ResBlockFused(Function):
                                                      _p(gb2), C, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()),
                        'res_block wgrad2')
         if need_x or need_w1 or need_b1:
-            # gradient w.r.t. relu(conv1(x)); relu' is applied from h when it is consumed below
+            # gradient w.r.t. conv1's output: conv2's data gradient times relu'(h).  The mask is applied in that kernel's epilogue when it
+            # has one (8 x 64 tile; one extra read of h instead of a second read of h in BOTH consumers below), else by the consumers.
             gh = torch.empty_like(x)
-            _conv_fwd(L, _p(gout), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, None, _p(gh), C, None, 0, B, 3, 1, 1,
-                      ACT_NONE, 0.0, 0, H, W, 'res_block dgrad2', wparam=w2)
+            masked = _conv_fwd(L, _p(gout), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, _p(h), _p(gh), C, None, 0, B, 3, 1, 1,
+                               ACT_MASK, 0.0, 0, H, W, 'res_block dgrad2', wparam=w2) if _FUSE_GRAD_MASK else False
+            if not masked:
+                _conv_fwd(L, _p(gout), C, None, 0, None, 0.0, 0, H, W, _p(w2), None, None, _p(gh), C, None, 0, B, 3, 1, 1,
+                          ACT_NONE, 0.0, 0, H, W, 'res_block dgrad2', wparam=w2)
+            hmask = None if masked else _p(h)
             if need_w1 or need_b1:
                 gw1 = _pgrad(w1)
                 gb1 = _pgrad(ctx.bias_p[0]) if ctx.has_bias[0] else None
                 ws = _workspace(nb, x.device)
-                _lib.check(L.rvsr_conv2d_backward_weight(_p(x), C, None, 0, H, W, _p(gh), _p(h), 0.0, 0, H, W,
+                _lib.check(L.rvsr_conv2d_backward_weight(_p(x), C, None, 0, H, W, _p(gh), hmask, 0.0, 0, H, W,
                                                          _p(gw1), _p(gb1), C, B, 3, 1, H, W, 0, _p(ws), ws.numel(),
                                                          _stream()), 'res_block wgrad1')
             if need_x:
                 gx = torch.empty_like(x)
-                _conv_fwd(L, _p(gh), C, None, 0, _p(h), 0.0, 0, H, W, _p(w1), None, _p(gout), _p(gx), C, None, 0, B, 3, 1, 1,
+                _conv_fwd(L, _p(gh), C, None, 0, hmask, 0.0, 0, H, W, _p(w1), None, _p(gout), _p(gx), C, None, 0, B, 3, 1, 1,
                           ACT_NONE, 0.0, 0, H, W, 'res_block dgrad1', wparam=w1)
         return gx, gw1, gb1, gw2, gb2
 

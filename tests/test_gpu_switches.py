@@ -1,4 +1,4 @@
-"""Every developer switch that selects an older kernel generation or a fixed variant (realvsr_amd/csrc: RVSR_DCN_FWD, RVSR_DCN_BWD, RVSR_DCN_BWDW, RVSR_DCN3_HALO, RVSR_DCN5_HALO, RVSR_DCN_MT_WIDE, RVSR_CONV_WIDE, RVSR_CONV_FWD6, RVSR_XCD_SWIZZLE; realvsr_amd: RVSR_FLAT_GRAD_ADOPT, RVSR_PACK_CACHE, RVSR_GRAD_SINKS) still produces reference
+"""Every developer switch that selects an older kernel generation or a fixed variant (realvsr_amd/csrc: RVSR_DCN_FWD, RVSR_DCN_BWD, RVSR_DCN_BWDW, RVSR_DCN3_HALO, RVSR_DCN5_HALO, RVSR_DCN_MT_WIDE, RVSR_CONV_WIDE, RVSR_CONV_FWD6, RVSR_XCD_SWIZZLE; realvsr_amd: RVSR_FLAT_GRAD_ADOPT, RVSR_PACK_CACHE, RVSR_GRAD_SINKS, RVSR_FUSE_GRAD_MASK) still produces reference
 arithmetic: those kernels are also the fallbacks for geometries the newest ones do not cover.  The switches are read once per
 process, so each setting runs tests/switch_check.py in a subprocess.  -m gpu"""
 import os
@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SETTINGS = ['RVSR_DCN_FWD=2', 'RVSR_DCN_BWD=2', 'RVSR_DCN_BWD=3', 'RVSR_DCN_BWD=4',
             'RVSR_DCN_BWD=5', 'RVSR_DCN5_HALO=2', 'RVSR_DCN5_HALO=5', 'RVSR_DCN5_HALO=8', 'RVSR_DCN5_HALO=12', 'RVSR_DCN_BWDW=3',
             'RVSR_DCN_BWDW=2', 'RVSR_DCN_MT_WIDE=2', 'RVSR_XCD_SWIZZLE=0', 'RVSR_FLAT_GRAD_ADOPT=0', 'RVSR_DCN3_HALO=3', 'RVSR_DCN3_HALO=7',
-            'RVSR_DCN3_HALO=11', 'RVSR_CONV_WIDE=0', 'RVSR_PACK_CACHE=0', 'RVSR_CONV_FWD6=1']
+            'RVSR_DCN3_HALO=11', 'RVSR_CONV_WIDE=0', 'RVSR_PACK_CACHE=0', 'RVSR_CONV_FWD6=1', 'RVSR_FUSE_GRAD_MASK=0']
 
 
 @pytest.mark.parametrize('setting', SETTINGS)

@@ -19,6 +19,7 @@ ap.add_argument('--Co', type=int, default=64)
 ap.add_argument('--H', type=int, default=180)
 ap.add_argument('--W', type=int, default=320)
 ap.add_argument('--bwd', action='store_true')
+ap.add_argument('--no-act', action='store_true', help='no activation: the weight / data gradient kernels without the act mask')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
@@ -30,7 +31,7 @@ for it in range(a.iters + 1):
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-    y = RF.conv2d(x, conv, RF.ACT_LRELU)
+    y = RF.conv2d(x, conv, RF.ACT_NONE if a.no_act else RF.ACT_LRELU)
     if a.bwd:
         y.backward(gout)
 e.record()
