@@ -95,33 +95,37 @@ class PCD_Align(nn.Module):
         conv, up = RF.conv2d, RF.upsample_bilinear
         sk = sinks if (sinks is not None and ref_repeat is not None) else [None, None, None]
         if ref_repeat is not None:
-            def cat_ref(x, cv, level, x_sink=None, x_owner=False):
+            def cat_ref(x, cv, level, x_sink=None, x_owner=False, premasked=False):
                 return RF.conv_cat_bcast(x, ref_fea_l[level], cv, ref_repeat, LRELU, x_sink=x_sink, x_owner=x_owner,
-                                         ref_sink=sk[level], ref_block=ref_block)
+                                         ref_sink=sk[level], ref_block=ref_block, grad_premasked=premasked)
         else:
-            def cat_ref(x, cv, level, x_sink=None, x_owner=False):
-                return conv(x, cv, LRELU, x2=ref_fea_l[level])
+            def cat_ref(x, cv, level, x_sink=None, x_owner=False, premasked=False):
+                return conv(x, cv, LRELU, x2=ref_fea_l[level], grad_premasked=premasked)
+        # Single-consumer chains conv -> LeakyReLU -> conv (L3 conv1 -> conv2, L2 / L1 conv2 -> conv3, L1 conv3 -> pack, cascade conv1 -> conv2 -> pack): where the consumer's data-gradient kernel has the mask epilogue (full-resolution
+        # level: functional.grad_mask_fusable) the producer's lrelu' is applied THERE (x_premask / feat_premask) and the producer's own
+        # backward runs without masks (grad_premasked) -- one read of the activation instead of one in each of its two gradient kernels.
+        pm = [(LRELU, 0.1) if RF.grad_mask_fusable(f.shape[2], f.shape[3]) else None for f in nbr_fea_l]
         # level 3 (this conv is the first consumer of the L3 features: it owns their sink)
-        L3_offset = cat_ref(nbr_fea_l[2], self.L3_offset_conv1, 2, sk[2], True)
-        L3_offset = conv(L3_offset, self.L3_offset_conv2, LRELU)
+        L3_offset = cat_ref(nbr_fea_l[2], self.L3_offset_conv1, 2, sk[2], True, premasked=pm[2] is not None)
+        L3_offset = conv(L3_offset, self.L3_offset_conv2, LRELU, x_premask=pm[2])   # (its own output has two consumers: the pack and level 2)
         L3_fea = self.L3_dcnpack([nbr_fea_l[2], L3_offset], act=LRELU, sink=sk[2])
         # level 2
         L2_offset = cat_ref(nbr_fea_l[1], self.L2_offset_conv1, 1, sk[1])
-        L2_offset = conv(L2_offset, self.L2_offset_conv2, LRELU, x2=up(L3_offset, 2, 2.0))
-        L2_offset = conv(L2_offset, self.L2_offset_conv3, LRELU)
+        L2_offset = conv(L2_offset, self.L2_offset_conv2, LRELU, x2=up(L3_offset, 2, 2.0), grad_premasked=pm[1] is not None)
+        L2_offset = conv(L2_offset, self.L2_offset_conv3, LRELU, x_premask=pm[1])   # (two consumers of its output: the pack and level 1)
         L2_fea = self.L2_dcnpack([nbr_fea_l[1], L2_offset], sink=sk[1])
         L2_fea = conv(L2_fea, self.L2_fea_conv, LRELU, x2=up(L3_fea, 2))
         # level 1
         L1_offset = cat_ref(nbr_fea_l[0], self.L1_offset_conv1, 0, sk[0])
-        L1_offset = conv(L1_offset, self.L1_offset_conv2, LRELU, x2=up(L2_offset, 2, 2.0))
-        L1_offset = conv(L1_offset, self.L1_offset_conv3, LRELU)
-        L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset], sink=sk[0])
+        L1_offset = conv(L1_offset, self.L1_offset_conv2, LRELU, x2=up(L2_offset, 2, 2.0), grad_premasked=pm[0] is not None)
+        L1_offset = conv(L1_offset, self.L1_offset_conv3, LRELU, x_premask=pm[0], grad_premasked=pm[0] is not None)
+        L1_fea = self.L1_dcnpack([nbr_fea_l[0], L1_offset], sink=sk[0], feat_premask=pm[0])
         L1_fea = conv(L1_fea, self.L1_fea_conv, x2=up(L2_fea, 2))  # no activation (EDVR_arch.py:125)
         # cascading DCN: L1_fea feeds the offset conv (owner of its sink) and the DCN
         cas_sink = RF.GradSink() if (ref_repeat is not None and sinks is not None) else None
-        offset = cat_ref(L1_fea, self.cas_offset_conv1, 0, cas_sink, True)
-        offset = conv(offset, self.cas_offset_conv2, LRELU)
-        return self.cas_dcnpack([L1_fea, offset], act=LRELU, sink=cas_sink)
+        offset = cat_ref(L1_fea, self.cas_offset_conv1, 0, cas_sink, True, premasked=pm[0] is not None)
+        offset = conv(offset, self.cas_offset_conv2, LRELU, x_premask=pm[0], grad_premasked=pm[0] is not None)
+        return self.cas_dcnpack([L1_fea, offset], act=LRELU, sink=cas_sink, feat_premask=pm[0])
 
 
 class TSA_Fusion(nn.Module):

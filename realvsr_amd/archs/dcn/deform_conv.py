@@ -113,8 +113,9 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         self.conv_offset_mask.weight.data.zero_()
         self.conv_offset_mask.bias.data.zero_()
 
-    def forward(self, x, act=RF.ACT_NONE, slope=0.1, sink=None):
-        """act / slope / sink are extensions (fused LeakyReLU epilogue; functional.GradSink of the sampled input)."""
+    def forward(self, x, act=RF.ACT_NONE, slope=0.1, sink=None, feat_premask=None):
+        """act / slope / sink / feat_premask are extensions (fused LeakyReLU epilogue; functional.GradSink of the sampled input; (act, slope)
+        of the activation that produced the offset features when this pack is their only consumer, functional.conv2d x_premask)."""
         if self.extra_offset_mask:  # x = [input, features]
             x, feat = x[0], x[1]
         else:
@@ -122,7 +123,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         fused = (self.kernel_size == (3, 3) and self.groups == 1 and
                  self.padding == self.dilation * (self.kernel_size[0] // 2))
         if fused:
-            om = RF.conv2d(feat, self.conv_offset_mask)
+            om = RF.conv2d(feat, self.conv_offset_mask, x_premask=feat_premask)
             return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                self.deformable_groups, act, slope, sink)
         if self.kernel_size == (3, 3) and self.padding == 1 and self.dilation == 1 and act == RF.ACT_NONE and sink is None:

@@ -278,7 +278,16 @@ class _Conv2dFused(Function):
     """act(conv2d(cat(x1, x2), w) + b) [+ residual] [-> PixelShuffle(2)]"""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle, sink=None, dep_sink=None):
+    def forward(ctx, x1, x2, weight, bias, residual, stride, act, slope, pixel_shuffle, sink=None, dep_sink=None, x_premask=None,
+                grad_premasked=False):
+        # x_premask = (act, slope) of the activation that PRODUCED x1, given when this conv is x1's only consumer: the data gradient then
+        # leaves this node already multiplied by act'(x1) (in the dgrad kernel's epilogue where it has one, rvsr_conv2d_forward act = 3),
+        # and the producer, called with grad_premasked=True, applies no mask in its own backward -- one read of x1 instead of a read of
+        # the producer's output in both of its gradient kernels.  (Multiplying by act' is linear, so it commutes with autograd's sum over
+        # consumers; the pairing is still only set up for single-consumer chains, archs/EDVR_arch.py.)
+        if x_premask is not None and (x2 is not None or sink is not None or dep_sink is not None or pixel_shuffle or stride != 1):
+            raise RuntimeError('conv2d: x_premask is for single-input stride-1 convs without a GradSink')
+        ctx.x_premask, ctx.grad_premasked = x_premask, bool(grad_premasked)
         if x2 is not None and (sink is not None or dep_sink is not None):
             # an owner that never closes drops what the depositors wrote: sinks are for single-input convs only
             raise RuntimeError('conv2d: a GradSink cannot be combined with a second (concatenated) input')
@@ -315,6 +324,8 @@ class _Conv2dFused(Function):
         B, Co = x1.shape[0], weight.shape[0]
         L = _lib.lib()
         gslope = 0.0 if act == ACT_RELU else slope
+        if ctx.grad_premasked:
+            act_out = None   # gout arrives multiplied by act'(out) already (the consumer's x_premask)
         need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gx1 = gx2 = gw = gb = None
         if ctx.sink is not None and not need_x1:
@@ -329,9 +340,18 @@ class _Conv2dFused(Function):
             gx1 = dep if dep is not None else torch.empty_like(x1)
             gx2 = torch.empty_like(x2) if x2 is not None else None
             in_mode = 2 if ps else (1 if stride == 2 else 0)
-            _conv_fwd(L, _p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2], gout.shape[3], _p(weight), None,
-                      _p(dep), _p(gx1), C1, _p(gx2), C2, B, k, 1, 1, ACT_NONE, 0.0, 0, H, W, 'conv2d_backward_data',
-                      wparam=weight)
+            masked = False
+            if ctx.x_premask is not None:
+                pslope = 0.0 if ctx.x_premask[0] == ACT_RELU else ctx.x_premask[1]
+                masked = _FUSE_GRAD_MASK and k == 3 and _conv_fwd(
+                    L, _p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2], gout.shape[3], _p(weight), None, _p(x1), _p(gx1),
+                    C1, None, 0, B, k, 1, 1, ACT_MASK, pslope, 0, H, W, 'conv2d_backward_data', wparam=weight)
+            if not masked:
+                _conv_fwd(L, _p(gout), Co, None, 0, _p(act_out), gslope, in_mode, gout.shape[2], gout.shape[3], _p(weight), None,
+                          _p(dep), _p(gx1), C1, _p(gx2), C2, B, k, 1, 1, ACT_NONE, 0.0, 0, H, W, 'conv2d_backward_data',
+                          wparam=weight)
+                if ctx.x_premask is not None:   # no fused epilogue for this frame / GEMM mode: the mask as a separate pass (the producer applies none)
+                    gx1.mul_(torch.where(x1 > 0, 1.0, pslope))
             if deposit:   # the first depositor's output IS the sink's buffer (no zero fill); autograd gets no gradient from here
                 ctx.dep_sink.buf = gx1
                 gx1 = None
@@ -345,7 +365,7 @@ class _Conv2dFused(Function):
                                                      Co, B, k, stride, Ho, Wo, 0, _p(ws), ws.numel(), _stream()),
                        'conv2d_backward_weight')
         gres = gout if has_res else None
-        return gx1, gx2, gw, gb, gres, None, None, None, None, None, None
+        return gx1, gx2, gw, gb, gres, None, None, None, None, None, None, None, None
 
 
 class _ResBlockFused(Function):
@@ -427,7 +447,8 @@ class _ConvCatBcast(Function):
     one reduction over N backward; act' is taken from the saved output as everywhere else."""
 
     @staticmethod
-    def forward(ctx, x, ref, weight, bias, N, act, slope, x_sink=None, x_owner=False, ref_sink=None, ref_block=0):
+    def forward(ctx, x, ref, weight, bias, N, act, slope, x_sink=None, x_owner=False, ref_sink=None, ref_block=0, grad_premasked=False):
+        ctx.grad_premasked = bool(grad_premasked)   # the only consumer multiplies its data gradient by act'(out) (conv2d x_premask)
         _need_cuda(x, ref, weight, bias)
         x, ref, weight, bias = _c(x), _c(ref), _c(weight), _c(bias)
         # GradSinks (see GradSink): x_sink collects the gradient of x (this conv deposits, or owns it when x_owner);
@@ -464,6 +485,8 @@ class _ConvCatBcast(Function):
         Co = w_a.shape[0]
         L = _lib.lib()
         gslope = 0.0 if act == ACT_RELU else slope
+        if ctx.grad_premasked:
+            act_out = None
         gx = gref = gw = gb = None
         # gradient of the broadcast partial: sum over the N frames of gout * act'
         gpart = x.new_empty(B, Co, H, W)
@@ -503,12 +526,12 @@ class _ConvCatBcast(Function):
             _lib.check(L.rvsr_conv2d_backward_weight(_p(ref), C2, None, 0, H, W, _p(gpart), None, 0.0, 0, H, W, _p(gw_b), None,
                                                      Co, B, 3, 1, H, W, 0, _p(ws), ws.numel(), _stream()), 'conv_cat_bcast wgrad_b')
             gw = torch.cat([gw_a, gw_b], 1)
-        return gx, gref, gw, gb, None, None, None, None, None, None, None
+        return gx, gref, gw, gb, None, None, None, None, None, None, None, None
 
 
-def conv_cat_bcast(x, ref, conv, N, act=ACT_NONE, slope=0.1, x_sink=None, x_owner=False, ref_sink=None, ref_block=0):
+def conv_cat_bcast(x, ref, conv, N, act=ACT_NONE, slope=0.1, x_sink=None, x_owner=False, ref_sink=None, ref_block=0, grad_premasked=False):
     """act(conv(cat([x, ref.repeat(N, 1, 1, 1)], 1))) for frame-major x [N*B, ...] and ref [B, ...] (3x3, stride 1)."""
-    return _ConvCatBcast.apply(x, ref, conv.weight, conv.bias, int(N), act, float(slope), x_sink, x_owner, ref_sink, ref_block)
+    return _ConvCatBcast.apply(x, ref, conv.weight, conv.bias, int(N), act, float(slope), x_sink, x_owner, ref_sink, ref_block, grad_premasked)
 
 
 def res_block(x, conv1, conv2):
@@ -516,7 +539,8 @@ def res_block(x, conv1, conv2):
     return _ResBlockFused.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
 
 
-def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False, sink=None, dep_sink=None):
+def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuffle=False, sink=None, dep_sink=None, x_premask=None,
+           grad_premasked=False):
     """Fused conv block driven by an ``nn.Conv2d`` parameter holder (weight, bias, stride).
 
     out = act(conv(cat(x, x2))) [+ residual]; with ``pixel_shuffle`` the activation commutes with
@@ -524,9 +548,19 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
     stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
     if residual is not None and act != ACT_NONE:
         # act'(.) is recovered from the saved activation output, so the residual is added outside
-        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle, sink, dep_sink)
+        out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle, sink, dep_sink, x_premask,
+                                 grad_premasked)
         return out + residual
-    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle, sink, dep_sink)
+    return _Conv2dFused.apply(x, x2, conv.weight, conv.bias, residual, stride, act, slope, pixel_shuffle, sink, dep_sink, x_premask,
+                              grad_premasked)
+
+
+def grad_mask_fusable(H, W):
+    """Whether the data-gradient kernel of a 3x3 stride-1 conv on H x W frames has the mask epilogue (the 8 x 64 tile: chosen when it
+    wastes no more pixels than 16 x 32, conv2_kernels.hip launch_fwd5).  Where it has not, x_premask costs a separate pass."""
+    px_n = ((H + 15) // 16 * 16) * ((W + 31) // 32 * 32)
+    px_w = ((H + 7) // 8 * 8) * ((W + 63) // 64 * 64)
+    return _FUSE_GRAD_MASK and W % 4 == 0 and px_w <= px_n
 
 
 # ------------------------------------------------------------------------------------------ DCN
