@@ -268,15 +268,19 @@ class _EDVRBase(nn.Module):
         else:   # what torch.stack(dim=1).view(B, -1, H, W) built (EDVR_arch.py:305-308)
             fea = conv(aligned_nb.transpose(0, 1).reshape(B, -1, H, W), self.tsa_fusion)
         out = self.recon_trunk(fea)
+        # single-consumer chains upconv2 -> HRconv -> conv_last: lrelu' of the producer in the consumer's data-gradient epilogue
+        # (functional.conv2d x_premask / grad_premasked; the pixel-unshuffle data gradient of upconv2 itself has no such epilogue)
         if self.upscale:
+            pm = (LRELU, 0.1) if RF.grad_mask_fusable(4 * H, 4 * W) else None
             out = conv(out, self.upconv1, LRELU, pixel_shuffle=True)
-            out = conv(out, self.upconv2, LRELU, pixel_shuffle=True)
-            out = conv(out, self.HRconv, LRELU)
+            out = conv(out, self.upconv2, LRELU, pixel_shuffle=True, grad_premasked=pm is not None)
+            out = conv(out, self.HRconv, LRELU, x_premask=pm, grad_premasked=pm is not None)
             base = x_center if self.HR_in else RF.upsample_bilinear(x_center, 4)   # EDVR_arch.py:314-317
         else:
-            out = conv(out, self.HRconv, LRELU)
+            pm = (LRELU, 0.1) if RF.grad_mask_fusable(H, W) else None
+            out = conv(out, self.HRconv, LRELU, grad_premasked=pm is not None)
             base = x_center
-        return conv(out, self.conv_last, residual=base)
+        return conv(out, self.conv_last, residual=base, x_premask=pm)
 
     def forward(self, x):
         B, N, C, H, W = x.size()  # N video frames
