@@ -14,10 +14,13 @@ train-step harness realvsr_amd.VideoSR_model.VideoSRModel.optimize_parameters --
 1.0 * GWLoss(w=4) on CbCr (the criteria 'lappyr' / 'gw' of the shipped option files), backward, Adam(0.9, 0.99).
 `--lf-mode cb` swaps the (third-party, parity-unpinned) SSIM low-frequency term for the in-tree Charbonnier one.
 Synthetic data: x ~ U[0,1) seed 1234, GT ~ U[0,1) seed 1235, default module init under seed 0 with
-conv_offset_mask.weight ~ N(0, 0.01^2).  With that init the deformable offsets are ~0.004 px; `--offset-px P`
-rescales the offset rows of every conv_offset_mask so that the mean |offset| of each DCN is P px (trained EDVR: several
-px); the line reports the measured offset statistics either way.  Weak scaling: every rank processes its own B
-windows; value = N*B*K / time.
+conv_offset_mask.weight ~ N(0, 0.01^2).  With that init alone the deformable offsets are ~0.004 px, which flatters the
+gather (SURVEY.md 8d asks for O(1) px), so by DEFAULT the offset rows of every conv_offset_mask are rescaled until the mean
+|offset| of each DCN is 1 px (`--offset-px P` for another value, `--offset-px 0` keeps the raw init; i.i.d. per pixel, i.e.
+harsher than a trained, spatially smooth field); the line reports the measured offset statistics, and `offset_sweep`
+carries the raw-init (~0 px) and 3 px steps.  Weak scaling: every rank processes its own B windows; value = N*B*K / time.
+`--config {2,3,5}` selects a BASELINE.json configuration: 2 (default) = EDVR-M nf64 / 5 frames / B 8; 3 = nf128 / 7 frames /
+B 16 (per GPU: with --gpus 8 this is BASELINE config 4); 5 = 540x960 sliding-window inference (fwd only, replicas).
 
 Extra objects on the line:
   roofline     -- the fused DCN forward kernel (the kernel north_star grades): algorithmic bytes 4*(C+216+Co) per
@@ -28,6 +31,10 @@ Extra objects on the line:
                   work issued (3 bf16 passes per product) vs the 2.5 PFLOP/s dense bf16 peak, and the f32-equivalent rate.
   cpu_baseline -- the CPU oracle (oracle/edvr_oracle.py, kind "port") on ONE window of the same workload (B=1),
                   1 warm-up + best-of-3, timed on this box's host cores (rank 0, N=1 only).
+  parity       -- the same seeded window, same weights, through the HIP model: output / loss / every parameter gradient against
+                  the oracle run that produced cpu_baseline (the oracle is the checker here, never the thing measured).
+  extra        -- driver-timed side lines (rank 0, N=1): config3 (nf128 / 7 frames / B 16 training step) and config5 (10-frame
+                  540x960 clip through infer.SlidingWindowRunner, eager and hipGraph), each with its own DCN-forward roofline.
 """
 import argparse
 import json
@@ -249,22 +256,36 @@ def timed_steps(model, n, first_step):
     return 1e3 * dt / n, frac, timer.backward_ms() / n
 
 
-def offset_sweep(model, x, first_step, pxs=(1.0, 3.0), steps=3):
-    """SURVEY.md 8d "second large-motion set", on the driver-timed line: the same step with every conv_offset_mask rescaled to a
-    mean |offset| of P px (i.i.d. per pixel: harsher than trained, spatially smooth fields), 2 untimed + `steps` timed
-    steps each, parameters and optimizer state restored afterwards.  dcn_bwd_ms = HIP-event time of the fused DCN backward
-    calls (input/offset/mask gradient + weight gradient kernels) per step."""
+def offset_sweep(model, x, first_step, native, pxs=(3.0,), steps=3):
+    """SURVEY.md 8d "second large-motion set", on the driver-timed line: the same step with the raw conv_offset_mask init (`native`:
+    the rows saved before the default rescale, mean |offset| ~0.004 px -- the flattering end) and with every conv_offset_mask rescaled to
+    a mean |offset| of P px (i.i.d. per pixel: harsher than trained, spatially smooth fields), 3 untimed + `steps` timed steps each,
+    parameters and optimizer state restored afterwards.  dcn_bwd_ms = HIP-event time of the fused DCN backward calls (input/offset/mask
+    gradient + weight gradient kernels) per step."""
+    from realvsr_amd import functional as RF
     out = {}
     snap = _Snapshot(model)
-    for P in pxs:
-        offset_stats(model.netG, x, P)
+
+    def entry(key):
         ms, frac, bwd = timed_steps(model, steps, first_step)
         st = offset_stats(model.netG, x)
         l1 = st.get('pcd_align.L1_dcnpack', (None, None))
-        out['%gpx' % P] = {'ms_per_step': round(ms, 3), 'dcn_fwd_frac': None if frac is None else round(frac, 4),
-                           'dcn_bwd_ms': round(bwd, 3), 'steps': steps,
-                           'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3)}
+        out[key] = {'ms_per_step': round(ms, 3), 'dcn_fwd_frac': None if frac is None else round(frac, 4),
+                    'dcn_bwd_ms': round(bwd, 3), 'steps': steps,
+                    'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3)}
         snap.restore()
+
+    if native:
+        with torch.no_grad():
+            for name, pack in dcn_packs(model.netG):
+                w, b = native[name]
+                pack.conv_offset_mask.weight.copy_(w)
+                pack.conv_offset_mask.bias.copy_(b)
+        RF.packed_weights.repack()
+        entry('raw_init')
+    for P in pxs:
+        offset_stats(model.netG, x, P)
+        entry('%gpx' % P)
     return out
 
 
@@ -282,18 +303,23 @@ def f32_mode_step(model, first_step, steps=2):
     return round(ms, 3)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, sd_in=None):
     """One window (B=1) of the same workload through the CPU oracle: fwd + loss + bwd; BASELINE.md section 2 protocol
-    (1 warm-up, then best of 3)."""
+    (1 warm-up, then best of 3).  `sd_in`: the benchmarked model's state_dict (so the CPU side runs the weights -- and the
+    offsets -- the GPU side was timed on); default: the module init.  Returns (json object, oracle results of the last run) --
+    the second feeds `parity_check`."""
     from oracle import edvr_oracle as O
     from realvsr_amd.archs.EDVR_arch import EDVR
     nf, N, H, W = args.nf, args.nframes, args.height, args.width
-    torch.manual_seed(0)
-    net = EDVR(nf=nf, nc=3, nframes=N, groups=8, front_RBs=5, back_RBs=args.back_rbs, w_TSA=True)
-    init_weights(net)
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    if sd_in is None:
+        torch.manual_seed(0)
+        net = EDVR(nf=nf, nc=3, nframes=N, groups=8, front_RBs=5, back_RBs=args.back_rbs, w_TSA=True)
+        init_weights(net)
+        sd_in = net.state_dict()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in sd_in.items()}
     x = torch.rand(1, N, 3, H, W, generator=torch.Generator().manual_seed(1234))
     gt = torch.rand(1, 3, 4 * H, 4 * W, generator=torch.Generator().manual_seed(1235))
+    last = {}
 
     def one():
         for v in sd.values():
@@ -302,7 +328,9 @@ def cpu_baseline(args):
         out = O.edvr_forward(sd, x, nframes=N, groups=8, front_RBs=5, back_RBs=args.back_rbs, w_TSA=True)
         loss = O.lap_pyr_loss(out[:, 0:1], gt[:, 0:1], 3, lf_mode=args.lf_mode) + O.gw_loss(out[:, 1:3], gt[:, 1:3], 4)
         loss.backward()
-        return time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        last['out'], last['loss'] = out.detach(), float(loss.item())
+        return dt
 
     # Thread count: min(hardware threads, 32).  The torch CPU conv path collapses from oversubscription on this host: the same
     # window took 432 s with all 256 hardware threads and 8.4 s with 32 (measured by an earlier version of this function, see
@@ -312,6 +340,8 @@ def cpu_baseline(args):
     torch.set_num_threads(cores)
     one()                                       # warm-up
     best = min(one() for _ in range(3))
+    last['grads'] = {k: v.grad.detach() for k, v in sd.items() if v.grad is not None}
+    last['x'], last['gt'] = x, gt
     cpu_model = ''
     try:
         with open('/proc/cpuinfo') as f:
@@ -320,8 +350,133 @@ def cpu_baseline(args):
         pass
     return {'value': round(1.0 / best, 5), 'unit': 'HR frames/s', 'cores': cores, 'kind': 'port',
             'sample': '1 window (B=1, %d frames %dx%d LR) fwd+loss+bwd through oracle/edvr_oracle.py (torch %s CPU ops + '
-                      'OpenMP C DCN); 1 warm-up + best of 3 = %.2f s; %d threads on a host with %d hardware threads (%s)'
-                      % (N, H, W, torch.__version__, best, cores, ncpu, cpu_model)}
+                      'OpenMP C DCN) on the weights the GPU step was timed on; 1 warm-up + best of 3 = %.2f s; %d threads on a '
+                      'host with %d hardware threads (%s)' % (N, H, W, torch.__version__, best, cores, ncpu, cpu_model)}, last
+
+
+def parity_check(model, ora):
+    """The oracle's window (same seeded input, same weights) through the HIP model: forward, the model's own criteria, backward
+    (no optimizer step); output / loss / per-parameter gradients against the oracle's.  Errors are relative L2 norms
+    (|a - b| / |b|); `out_max_abs_err` is the largest element-wise difference of the [0, 1]-range output."""
+    dev = model.device
+    keep_L, keep_H = getattr(model, 'var_L', None), getattr(model, 'var_H', None)
+    model.feed_data({'LQs': ora['x'].to(dev), 'GT': ora['gt'].to(dev)})
+    model.optimizer_G.zero_grad()
+    total, _ = model.forward_loss()
+    total.backward()
+    torch.cuda.synchronize()
+
+    def l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / (b.norm() + 1e-300))
+
+    out = model.fake_H
+    worst, worst_name, num, den, missing = 0.0, None, 0.0, 0.0, []
+    for k, p in model.netG.named_parameters():
+        g = ora['grads'].get(k)
+        if g is None or p.grad is None:
+            missing.append(k)
+            continue
+        e = l2(p.grad, g)
+        num += float((p.grad.detach().double().cpu() - g.double()).pow(2).sum())
+        den += float(g.double().pow(2).sum())
+        if e > worst:
+            worst, worst_name = e, k
+    res = {'window': 'B=1, seeds 1234/1235, weights of the timed model', 'out_rel_err': float('%.3e' % l2(out, ora['out'])),
+           'out_max_abs_err': float('%.3e' % (out.detach().cpu() - ora['out']).abs().max().item()),
+           'loss_rel_err': float('%.3e' % (abs(float(total.item()) - ora['loss']) / max(abs(ora['loss']), 1e-30))),
+           'grad_l2_err_all': float('%.3e' % ((num / max(den, 1e-300)) ** 0.5)), 'worst_param': worst_name,
+           'worst_param_l2_err': float('%.3e' % worst), 'params_compared': len(ora['grads']) - len(missing),
+           'params_without_gradient': missing, 'checker': 'oracle/edvr_oracle.py (CPU)'}
+    model.optimizer_G.zero_grad()
+    if keep_L is not None:
+        model.var_L, model.var_H = keep_L, keep_H
+    return res
+
+
+class _Cfg:
+    """argparse-like bundle for the side lines."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def extra_train_line(base, nf, nframes, batch, steps=3):
+    """A second training configuration timed on the driver's box after the main line (BASELINE config 3: nf128 / 7 frames / B 16):
+    same harness, same offset protocol, 3 untimed + `steps` timed steps."""
+    from realvsr_amd import loss as L
+    from realvsr_amd.VideoSR_model import create_model
+    a = _Cfg(**dict(vars(base), nf=nf, nframes=nframes, batch=batch))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(0)
+    model = create_model(model_opt(a, 1))
+    init_weights(model.netG)
+    if a.lf_mode == 'cb':
+        model.cri_pix_y = L.LapPyrLoss(3, 'cb', 'cb', 'mean')
+    x, gt = make_batch(batch, nframes, a.height, a.width, dev)
+    if a.offset_px:
+        offset_stats(model.netG, x, a.offset_px)
+    model.feed_data({'LQs': x, 'GT': gt})
+    ms, frac, bwd = timed_steps(model, steps, 1)
+    st = offset_stats(model.netG, x)
+    l1 = st.get('pcd_align.L1_dcnpack', (None, None))
+    from realvsr_amd import _lib as rlib
+    conv = conv_roofline(model.netG, batch * nframes, nf, a.height, a.width, rlib.get_gemm_mode(), reps=3)
+    out = {'workload': 'EDVR nf%d, %d-frame %dx%d LR windows, batch %d, fwd + loss + bwd + Adam step' % (nf, nframes, a.height, a.width, batch),
+           'ms_per_step': round(ms, 2), 'value': round(batch / (ms * 1e-3), 3), 'unit': 'HR frames/s', 'steps': steps,
+           'dcn_fwd_frac': None if frac is None else round(frac, 4), 'dcn_bwd_ms_per_step': round(bwd, 2),
+           'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3), 'conv_frac_of_bf16_peak': conv['frac'],
+           'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    del model, x, gt
+    return out
+
+
+def infer_line(a, T=10, offset_px=None):
+    """BASELINE config 5: a T-frame 540x960 clip through infer.SlidingWindowRunner (per-frame feature reuse), forward only, eager and as
+    a hipGraph replay of the window stage; ms per 2160x3840 output frame and the DCN-forward roofline of the eager pass."""
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    from realvsr_amd.infer import SlidingWindowRunner
+    dev = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(0)
+    net = EDVR(nf=a.nf, nc=3, nframes=a.nframes, groups=8, front_RBs=5, back_RBs=a.back_rbs, w_TSA=True)
+    init_weights(net)
+    net = net.to(dev).eval()
+    clip = torch.rand(T, 3, a.height, a.width, generator=torch.Generator().manual_seed(1234)).to(dev)
+    if offset_px:
+        offset_stats(net, clip[:a.nframes].unsqueeze(0).contiguous(), offset_px)
+    st = offset_stats(net, clip[:a.nframes].unsqueeze(0).contiguous())
+    l1 = st.get('pcd_align.L1_dcnpack', (None, None))
+
+    def timed(run):
+        run(clip)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(clip)
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) * 1e3 / T
+
+    run = SlidingWindowRunner(net, a.nframes, padding='replicate', chunk=2)
+    out, ms_eager = timed(run)
+    timer = DcnTimer()
+    timer.install()
+    run(clip)
+    torch.cuda.synchronize()
+    timer.uninstall()
+    nl, kms, kbytes = timer.result()
+    run_g = SlidingWindowRunner(net, a.nframes, padding='replicate', chunk=2, use_graph=True)
+    out_g, ms_graph = timed(run_g)
+    res = {'workload': 'EDVR nf%d, %d-frame windows over a %d-frame %dx%d clip -> %dx%d, forward only, per-frame feature reuse'
+                       % (a.nf, a.nframes, T, a.height, a.width, 4 * a.height, 4 * a.width),
+           'ms_per_frame': round(min(ms_eager, ms_graph), 2), 'ms_per_frame_eager': round(ms_eager, 2),
+           'ms_per_frame_hipgraph': round(ms_graph, 2), 'value': round(1e3 / min(ms_eager, ms_graph), 3), 'unit': 'HR frames/s',
+           'graph_bit_identical': bool(torch.equal(out, out_g)),
+           'dcn_fwd_frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
+           'dcn_fwd_avg_launch_ms': round(kms / max(nl, 1), 4), 'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3),
+           'note': 'the eager pass is GPU-bound at this frame size (no launch gaps), so the hipGraph replay of the window stage has '
+                   'nothing to recover and pays for gathering the window into static buffers',
+           'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    del net, clip, out, out_g, run, run_g
+    return res
 
 
 def relaunch(args):
@@ -348,11 +503,24 @@ def main():
     ap.add_argument('--height', type=int, default=180)
     ap.add_argument('--width', type=int, default=320)
     ap.add_argument('--lf-mode', choices=['ssim', 'cb'], default='ssim')
-    ap.add_argument('--offset-px', type=float, default=None,
-                    help='rescale every conv_offset_mask so that the mean |offset| of its DCN is this many pixels')
+    ap.add_argument('--offset-px', type=float, default=1.0,
+                    help='rescale every conv_offset_mask so that the mean |offset| of its DCN is this many pixels (default 1; 0 = '
+                         'keep the raw N(0, 0.01^2) init, ~0.004 px)')
+    ap.add_argument('--config', type=int, choices=[2, 3, 5], default=2,
+                    help='BASELINE.json configuration: 2 = nf64 / 5 frames / B 8 (default), 3 = nf128 / 7 frames / B 16 per GPU '
+                         '(with --gpus 8: config 4), 5 = 540x960 sliding-window inference')
+    ap.add_argument('--no-extra', action='store_true', help='skip the config-3 / config-5 side lines')
+    ap.add_argument('--dry-run', action='store_true', help='N > 1: check launcher env, device count and backend, then exit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true', help='skip the post-run offset sweep and the f32-mode step')
+    pre, _ = ap.parse_known_args()
+    if pre.config == 3:
+        ap.set_defaults(nf=128, nframes=7, batch=16)
+    elif pre.config == 5:
+        ap.set_defaults(nf=128, nframes=7, batch=1, height=540, width=960)
     args = ap.parse_args()
+    if args.offset_px is not None and args.offset_px <= 0:
+        args.offset_px = None
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch(args)
@@ -366,7 +534,17 @@ def main():
     ndev = torch.cuda.device_count()
     backend = os.environ.get('RVSR_BENCH_BACKEND', 'nccl')  # 'gloo': developer check of the N>1 path on one GPU
     if backend == 'nccl' and world > ndev:
-        raise SystemExit('WORLD_SIZE=%d but only %d GPUs are visible (one rank per GPU)' % (world, ndev))
+        raise SystemExit('bench.py --gpus %d: WORLD_SIZE=%d ranks over RCCL need one MI355X each, but this box shows %d GPU(s) '
+                         '(HIP_VISIBLE_DEVICES=%s).  Run on a node with >= %d GPUs, or set RVSR_BENCH_BACKEND=gloo to exercise the '
+                         'N > 1 code path with all ranks sharing GPU 0 (developer check, not a scaling number).'
+                         % (args.gpus, world, ndev, os.environ.get('HIP_VISIBLE_DEVICES', '<unset>'), world))
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({'dry_run': True, 'world': world, 'visible_gpus': ndev, 'backend': backend,
+                              'master': '%s:%s' % (os.environ.get('MASTER_ADDR', '127.0.0.1'), os.environ.get('MASTER_PORT', '29511')),
+                              'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                              'bucket_mb': float(os.environ.get('RVSR_BUCKET_MB', '4'))}), flush=True)
+        return
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
@@ -385,6 +563,27 @@ def main():
     from realvsr_amd.VideoSR_model import create_model
     gemm_mode = rlib.get_gemm_mode()
     B, N, H, W = args.batch, args.nframes, args.height, args.width
+    if args.config == 5:
+        # inference replicas: every rank super-resolves its own clip, no collective on the data path
+        res = infer_line(args, T=10, offset_px=args.offset_px)
+        t = torch.tensor([res['ms_per_frame']], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            ms = t.item()
+            print(json.dumps({'metric': 'HR frames/sec (fwd only, sliding window) on %d-frame %dx%d LR windows' % (N, H, W),
+                              'value': round(world * 1e3 / ms, 3), 'unit': 'HR frames/s', 'n_gpus': world, 'steps': 10, 'warmup': 10,
+                              'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                              'dtype': 'f32 (bf16x3 GEMM)' if gemm_mode == 'bf16x3' else 'f32', 'data': 'synthetic',
+                              'config': {'workload': res['workload'], 'parallelism': 'replicas x%d' % world, 'gemm': gemm_mode,
+                                         'offset_abs_mean_px': res['offset_abs_mean_px']},
+                              'roofline': {'kernel': 'fused DCN forward', 'bound': 'hbm', 'frac': res['dcn_fwd_frac'], 'peak': HBM_PEAK_GBS,
+                                           'unit': 'GB/s', 'achieved': None if res['dcn_fwd_frac'] is None else round(res['dcn_fwd_frac'] * HBM_PEAK_GBS, 1),
+                                           'avg_launch_ms': res['dcn_fwd_avg_launch_ms'], 'traffic': None},
+                              'detail': res}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     torch.manual_seed(0 if rank == 0 else 12345 + rank)   # ranks > 0 start from DIFFERENT weights on purpose:
     model = create_model(model_opt(args, world))           # the model broadcasts rank 0's (checked below)
     if rank == 0:
@@ -400,6 +599,8 @@ def main():
     if args.lf_mode == 'cb':
         model.cri_pix_y = L.LapPyrLoss(3, 'cb', 'cb', 'mean')
     x, gt = make_batch(B, N, H, W, device, rank)
+    native = {name: (pack.conv_offset_mask.weight.detach().clone(), pack.conv_offset_mask.bias.detach().clone())
+              for name, pack in dcn_packs(model.netG)}   # the raw init, for the sweep's ~0 px entry
     if args.offset_px is not None and rank == 0:
         offset_stats(model.netG, x, args.offset_px)
     if args.offset_px is not None and world > 1:
@@ -501,13 +702,37 @@ def main():
         if allreduce is not None:
             line['allreduce'] = allreduce
         line['roofline_conv'] = conv_roofline(model.netG, B * N, args.nf, H, W, gemm_mode)
-        if world == 1 and not args.no_sweep and args.offset_px is None:
+        if world == 1 and not args.no_sweep:
             nxt = args.warmup + args.steps + 1
-            line['offset_sweep'] = offset_sweep(model, x, nxt)
+            line['offset_sweep'] = offset_sweep(model, x, nxt, native if args.offset_px is not None else None,
+                                                pxs=(3.0,) if args.offset_px is not None else (1.0, 3.0))
             if gemm_mode == 'bf16x3':
                 line['f32_mode_ms_per_step'] = f32_mode_step(model, nxt)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args)
+            line['cpu_baseline'], ora = cpu_baseline(args, model.netG.state_dict())
+            line['parity'] = parity_check(model, ora)
+            line['parity']['gemm'] = gemm_mode
+            del ora
+        if world == 1 and not args.no_extra and args.config == 2:
+            del model, x, gt, timer
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            extra = {}
+            try:
+                extra['config3'] = extra_train_line(args, 128, 7, 16)
+            except Exception as e:   # a side line must not cost the driver its main line
+                extra['config3'] = {'error': repr(e)[:300]}
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            try:
+                extra['config5'] = infer_line(_Cfg(nf=128, nframes=7, height=540, width=960, back_rbs=args.back_rbs), T=10,
+                                              offset_px=args.offset_px)
+            except Exception as e:
+                extra['config5'] = {'error': repr(e)[:300]}
+            line['extra'] = extra
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

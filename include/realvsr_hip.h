@@ -4,8 +4,16 @@
  *
  * Conventions (all entry points):
  *   - plain device pointers (float32, NCHW, contiguous unless a batch stride is stated) + sizes;
- *     no torch / ATen types.  The caller owns every buffer; the library keeps no global state
- *     and allocates nothing (temporaries come in through `workspace`).
+ *     no torch / ATen types.  The caller owns every buffer; the library allocates nothing
+ *     (temporaries come in through `workspace`) and keeps no state between calls EXCEPT one
+ *     process-wide setting, the GEMM arithmetic (rvsr_set_gemm_mode below: read by every conv /
+ *     DCN entry point at call time; set it once before the first call, not concurrently with
+ *     calls in flight on other host threads -- the reference's nn.DataParallel threads
+ *     (VideoSR_AllPair_model_YCbCr_Split.py:35-36) may all CALL concurrently, each on its own
+ *     device / stream; tests/test_gpu_misc.py::test_two_host_threads_two_streams).  The host
+ *     mirror realvsr_amd.functional keeps two per-process caches on top (bf16 weight images keyed
+ *     on the parameter object, per-layer DCN offset statistics); both are keyed per parameter
+ *     object + device, so DataParallel replicas (distinct parameter objects) get their own entries.
  *   - `stream` is a hipStream_t (NULL = default stream).  Launches are asynchronous; the call is
  *     re-entrant across devices/streams (the caller sets the current device, as
  *     at::DeviceGuard does in the reference: deform_conv_cuda.cpp:499,581).

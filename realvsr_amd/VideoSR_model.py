@@ -15,6 +15,7 @@ MI355X wiring instead of DataParallel / DistributedDataParallel + torch.optim.Ad
   * augmentation runs as one kernel on the device-resident clip pair (augment.apply_augment).
 Out of scope: LR schedulers, logging, checkpoint cadence, the VGG feature loss and the GAN models.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -93,7 +94,7 @@ class VideoSRModel:
                                     betas=(train_opt['beta1'], train_opt['beta2']))
         self.optimizers.append(self.optimizer_G)
         if self.dist:
-            self.reducer = BucketedGradAllReduce(None, bucket_mb=train_opt.get('bucket_mb', 4.0),
+            self.reducer = BucketedGradAllReduce(None, bucket_mb=float(os.environ.get('RVSR_BUCKET_MB', train_opt.get('bucket_mb', 4.0))),
                                                  buffers=self.optimizer_G.buffers, broadcast=False)
         self.log_dict = OrderedDict()
 

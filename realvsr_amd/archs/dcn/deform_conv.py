@@ -126,6 +126,10 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
             om = RF.conv2d(feat, self.conv_offset_mask, x_premask=feat_premask)
             return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                self.deformable_groups, act, slope, sink)
+        if feat_premask is not None:
+            # the producer of `feat` ran with grad_premasked=True and relies on THIS conv to apply its activation derivative:
+            # only the fused branch does
+            raise RuntimeError('ModulatedDeformConvPack: feat_premask needs the fused 3x3 / groups=1 path')
         if self.kernel_size == (3, 3) and self.padding == 1 and self.dilation == 1 and act == RF.ACT_NONE and sink is None:
             # groups > 1 (deform_conv.py:284-292 as written): the unfused wiring on the composed operator
             out = RF.conv2d(feat, self.conv_offset_mask)

@@ -398,7 +398,7 @@ int rvsr_launch_dcn_fwd3(const DcnFwdParams& p_in, const void* wpack, int mt, hi
     p.sel.ge = 1; p.sel.thr_ge = thr3; p.sel.lt = has11 ? 3 : -1; p.sel.thr_lt = thr7;
     FWD3_DISPATCH(7);
     if (rc != RVSR_OK || !has11) return rc;
-    p.sel.ge = 3; p.sel.thr_ge = thr7; p.sel.lt = -1;
+    p.sel.ge = 3; p.sel.thr_ge = thr7; p.sel.lt = -1; p.sel.ge2 = 1; p.sel.thr_ge2 = thr3;   // (a partition: not when R = 3 runs)
     FWD3_DISPATCH(11);
 #undef FWD3_DISPATCH
     return rc;

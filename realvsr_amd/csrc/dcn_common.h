@@ -74,18 +74,22 @@ __device__ __forceinline__ Samp dcn_sample(const DcnGeom& d, int b, int g, int k
 // probe[0..5] = sampled counts of offset components with |v| > 2.5 / 3.5 / 5.5 / 7.5 / 8.5 / 11.5 px (dcn_offset_probe2_kernel): the
 // backward's windows (2 / 5 / 8 / 12 px) use counters 0, 2, 4, the forward's tiles (3 / 7 / 11 px) counters 1, 3, 5.  probe == nullptr: run.
 #define DCN_PROBE_COUNTERS 6
+//   (ge < 0 || probe[ge] >= thr_ge) && (ge2 < 0 || probe[ge2] >= thr_ge2) && (lt < 0 || probe[lt] < thr_lt)
+// (two lower conditions: the candidates of a cascade "A while x < a, else B while y < b, else C" form a partition only if C also
+// carries "x >= a" -- a heavy-tailed offset field can have y >= b with x < a, and A and C would both run)
 struct DcnHaloSel {
     const unsigned* probe;
-    int ge, lt;
-    unsigned thr_ge, thr_lt;
+    int ge, lt, ge2;
+    unsigned thr_ge, thr_lt, thr_ge2;
 };
 __device__ __forceinline__ bool dcn_halo_not_selected(const DcnHaloSel& s) {
     if (s.probe == nullptr) return false;
     if (s.ge >= 0 && s.probe[s.ge] < s.thr_ge) return true;
+    if (s.ge2 >= 0 && s.probe[s.ge2] < s.thr_ge2) return true;
     if (s.lt >= 0 && s.probe[s.lt] >= s.thr_lt) return true;
     return false;
 }
-static inline DcnHaloSel dcn_halo_always() { DcnHaloSel s; s.probe = nullptr; s.ge = s.lt = -1; s.thr_ge = s.thr_lt = 0; return s; }
+static inline DcnHaloSel dcn_halo_always() { DcnHaloSel s; s.probe = nullptr; s.ge = s.lt = s.ge2 = -1; s.thr_ge = s.thr_lt = s.thr_ge2 = 0; return s; }
 
 struct DcnFwdParams {
     DcnGeom d;

@@ -18,7 +18,11 @@ different order -- or not at all -- still pair up the same collectives.
 import torch
 import torch.distributed as dist
 
+import os
+
 from .optim import FlatBuffers
+
+_DIST_CHECK = os.environ.get('RVSR_DIST_CHECK', '0') == '1'
 
 
 def broadcast_parameters(module_or_tensors, src=0, process_group=None):
@@ -109,8 +113,19 @@ class BucketedGradAllReduce:
         if self.flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        self.buffers.rebind()
+        self.buffers.rebind()            # (records FlatBuffers.no_grad first: the parameters FlatAdam.step must not move)
         self.buffers.check_bound()
+        if _DIST_CHECK:
+            # developer check: every rank skipped the same parameters (same autograd graph everywhere)
+            mine = torch.zeros(len(self.params), dtype=torch.int32, device=self.flat.device)
+            idx = {p: i for i, p in enumerate(self.params)}
+            for q in self.buffers.no_grad or []:
+                mine[idx[q]] = 1
+            lo, hi = mine.clone(), mine.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError('ranks disagree on which parameters received a gradient this step (data-dependent graph?)')
         for b in range(self._next, len(self.buckets)):   # buckets holding parameters that got no gradient this step
             self._pending[b] = 0
         self._issue_ready()

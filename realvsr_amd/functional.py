@@ -122,6 +122,9 @@ def _pgrad(p, zero=False):
 
 
 
+_PACK_VERIFY = os.environ.get('RVSR_PACK_VERIFY', '0') == '1'
+
+
 # ------------------------------------------------------------------------------------------ packed weights, once per step
 class PackedWeights:
     """bf16 hi/lo weight images (what the conv / DCN kernels stage into LDS), packed ONCE per optimizer step.
@@ -192,6 +195,8 @@ class PackedWeights:
         e = self.entries.get(key)
         if e is not None and e[1]() is weight and e[2] == self._version(weight) and e[3] == self.epoch and e[5] == weight.data_ptr():
             self.stats['hits'] += 1
+            if _PACK_VERIFY:
+                self._verify(e, weight, kind, C_in, Co, k, w_mode)
             return e[0]
         import weakref
         L = _lib.lib()
@@ -208,6 +213,20 @@ class PackedWeights:
         self.entries[key] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc), weight.data_ptr()]
         self.table = None
         return buf
+
+    def _verify(self, e, weight, kind, C_in, Co, k, w_mode):
+        """RVSR_PACK_VERIFY=1 (debug): on a cache hit, pack the weight again and compare -- catches writes that bypassed both torch's
+        version counter and repack()/invalidate() (p.data.copy_, raw writes into FlatBuffers.param, EMA swaps)."""
+        L = _lib.lib()
+        tmp = torch.empty_like(e[0])
+        if kind == 'conv':
+            n = L.rvsr_conv2d_pack_weights(_p(weight), C_in, Co, k, w_mode, _p(tmp), tmp.numel(), None, _stream())
+        else:
+            n = L.rvsr_dcn_pack_weights(_p(weight), C_in, Co, _p(tmp), tmp.numel(), None, _stream())
+        n = int(n)
+        if not torch.equal(tmp[:n], e[0][:n]):
+            raise RuntimeError('PackedWeights: stale bf16 weight image (the parameter was written without a version bump; call '
+                               'realvsr_amd.functional.invalidate_weight_cache() after such writes)')
 
     def repack(self):
         """Re-pack every live image in one launch (the parameters were just updated in place) and start a new epoch."""
@@ -255,6 +274,13 @@ class PackedWeights:
 packed_weights = PackedWeights()
 
 
+def invalidate_weight_cache():
+    """Call after writing parameters behind torch's version counter (``p.data.copy_``, raw writes into ``FlatBuffers.param``, an EMA
+    swap, a custom re-init after FlatAdam was built): forgets every cached bf16 weight image; the next use packs afresh.
+    ``load_state_dict`` / in-place ops under ``no_grad`` bump the version and need nothing; ``FlatAdam.step`` re-packs by itself."""
+    packed_weights.invalidate()
+
+
 def _conv_fwd(L, x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias, residual, out1, Co1, out2, Co2, B, k, stride, w_mode,
               act, slope, ps, Hout, Wout, what, wparam=None):
     """rvsr_conv2d_forward with the weight image from the per-step cache when `wparam` (the nn.Parameter behind `weight`,
@@ -287,6 +313,10 @@ class _Conv2dFused(Function):
         # consumers; the pairing is still only set up for single-consumer chains, archs/EDVR_arch.py.)
         if x_premask is not None and (x2 is not None or sink is not None or dep_sink is not None or pixel_shuffle or stride != 1):
             raise RuntimeError('conv2d: x_premask is for single-input stride-1 convs without a GradSink')
+        if grad_premasked and (act == ACT_NONE or residual is not None):
+            # the consumer multiplies by act'(this conv's OUTPUT): with a residual added (or no activation) the output is not an
+            # activation output and the pairing would silently drop / misapply the derivative
+            raise RuntimeError('conv2d: grad_premasked needs an activation and no residual on the producing conv')
         ctx.x_premask, ctx.grad_premasked = x_premask, bool(grad_premasked)
         if x2 is not None and (sink is not None or dep_sink is not None):
             # an owner that never closes drops what the depositors wrote: sinks are for single-input convs only
@@ -470,6 +500,9 @@ class _ConvCatBcast(Function):
         _lib.check(L.rvsr_bcast_add_act(_p(out), _p(part), part.numel(), N, act, slope, _stream()), 'bcast_add_act')
         ctx.cfg = (N, act, slope, bias is not None)
         ctx.w_ab = (w_a, w_b)   # (python references: the cached slices carry the attribute the weight-image cache keys on)
+        # the cached slices are PERSISTENT tensors that repack() / split() overwrite in place, behind save_for_backward's version
+        # check: remember what they were copied from, backward refuses to run on newer weights
+        ctx.w_tag = (weight._version, packed_weights.epoch if getattr(w_a, '_rvsr_parent', None) is not None else None)
         ctx.save_for_backward(x, ref, out if act != ACT_NONE else None)
         return out
 
@@ -478,6 +511,11 @@ class _ConvCatBcast(Function):
     def backward(ctx, gout):
         x, ref, act_out = ctx.saved_tensors
         w_a, w_b = ctx.w_ab
+        if ctx.w_tag[1] is not None:
+            parent = w_a._rvsr_parent()
+            if parent is None or parent._version != ctx.w_tag[0] or packed_weights.epoch != ctx.w_tag[1]:
+                raise RuntimeError('conv_cat_bcast: the weights were modified (optimizer step / in-place write) between this forward '
+                                   'and its backward')
         N, act, slope, has_bias = ctx.cfg
         gout = gout.contiguous()
         NB, C1, H, W = x.shape
@@ -546,6 +584,8 @@ def conv2d(x, conv, act=ACT_NONE, slope=0.1, x2=None, residual=None, pixel_shuff
     out = act(conv(cat(x, x2))) [+ residual]; with ``pixel_shuffle`` the activation commutes with
     the shuffle, so lrelu(pixel_shuffle(conv(x))) (EDVR_arch.py:311-312) is one kernel."""
     stride = conv.stride[0] if isinstance(conv.stride, tuple) else conv.stride
+    if grad_premasked and residual is not None:
+        raise RuntimeError('conv2d: grad_premasked cannot be combined with a residual (out + residual is not an activation output)')
     if residual is not None and act != ACT_NONE:
         # act'(.) is recovered from the saved activation output, so the residual is added outside
         out = _Conv2dFused.apply(x, x2, conv.weight, conv.bias, None, stride, act, slope, pixel_shuffle, sink, dep_sink, x_premask,

@@ -58,6 +58,10 @@ class FlatBuffers:
         # ids of the parameters whose flat gradient view a fused backward has been given since the last zero_grad
         # (functional._pgrad hands a home out once; see there)
         self.claimed = set()
+        # parameters that had received no gradient when rebind() first ran after the last zero_grad (None = not decided yet):
+        # what FlatAdam.step must leave untouched.  Decided BEFORE rebind() hands every parameter a flat view -- with world > 1 the
+        # reducer's finish() rebinds ahead of the optimizer, and `p.grad is None` would never be seen by step() otherwise.
+        self.no_grad = None
         with torch.no_grad():
             for p in self.order:
                 o, n = self.offset[p], p.numel()
@@ -81,13 +85,19 @@ class FlatBuffers:
         Gradients that arrive from elsewhere (plain torch modules) are copied home by ``rebind``."""
         self.grad.zero_()
         self.claimed.clear()
+        self.no_grad = None
         for p in self.order:
             p.grad = None
 
     def rebind(self, p=None):
         """Make ``p.grad`` (all parameters if None) the flat view again: zeros if no gradient arrived, a copy if autograd
         adopted a tensor that lives elsewhere.  A home that a fused backward wrote but autograd never adopted
-        (``torch.autograd.grad``: the result went to the caller, not to ``p.grad``) is not a gradient of this step: zeroed."""
+        (``torch.autograd.grad``: the result went to the caller, not to ``p.grad``) is not a gradient of this step: zeroed.
+        The first whole-buffer call after a zero_grad records which parameters had no gradient (``no_grad``).  With several ranks
+        that set must be the same everywhere (the same graph on every rank -- DistributedDataParallel's own requirement without
+        find_unused_parameters); RVSR_DIST_CHECK=1 makes BucketedGradAllReduce.finish() verify it."""
+        if p is None and self.no_grad is None:
+            self.no_grad = [q for q in self.order if q.grad is None]
         for q in (self.order if p is None else (p,)):
             o = self.offset[q]
             if q.grad is None:
@@ -155,7 +165,9 @@ class FlatAdam(torch.optim.Optimizer):
         if len(self.state) == 0:          # a scheduler cleared the state (restart): start the moments over
             self.reset_state()
         # torch skips parameters without a gradient; the flat launch touches every element, so keep what must not move
-        skipped = [(o, o + p.numel()) for p, o in self.buffers.offset.items() if p.grad is None]
+        if self.buffers.no_grad is None:       # (else: the gradient all-reduce already rebound every parameter and recorded the set)
+            self.buffers.no_grad = [p for p in self.buffers.order if p.grad is None]
+        skipped = [(self.buffers.offset[p], self.buffers.offset[p] + p.numel()) for p in self.buffers.no_grad]
         saved = [(s, e, self.buffers.param[s:e].clone(), self.exp_avg[s:e].clone(), self.exp_avg_sq[s:e].clone())
                  for s, e in skipped]
         self.buffers.rebind()
