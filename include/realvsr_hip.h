@@ -185,7 +185,9 @@ int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const 
  *   rvsr_conv2d_pack_weights / rvsr_dcn_pack_weights write the image of one layer (forward: w_mode 0, data gradient: w_mode 1) to
  *   caller-owned memory of rvsr_conv2d_forward_workspace_bytes(C_in, 0, Co, ksize) /
  *   rvsr_modulated_deform_conv_forward_workspace_bytes(channels, channels_out) bytes and return that size (0 = bad argument);
- *   `desc` (NULL or 10 x long long, host) receives {weight, out, Co, C_in, taps, MP, CCG, nchunks, nmb, mode}.
+ *   `desc` (NULL or 10 x long long, host; 20 x long long for rvsr_dcn_pack_weights) receives {weight, out, Co, C_in, taps, MP, CCG,
+ *   nchunks, nmb, mode}.  The DCN forward keeps TWO images in that buffer -- the tap-major one of dcn_fwd2 / dcn_fwd3 (mode 0)
+ *   and, behind it, the k-step-major one of dcn_fwd4 (mode 2; desc[10..19], all zero where that kernel does not apply: C % 16 != 0).
  *   rvsr_pack_weights_batched re-packs n images in ONE launch from a DEVICE table of 48-byte records
  *   {const float* w; void* out; int Co, C_in, taps, MP, CCG, nchunks, nmb, mode;} built from those descriptors: the host
  *   (realvsr_amd.functional.PackedWeights) calls it once after the optimizer has updated the parameters in place. */

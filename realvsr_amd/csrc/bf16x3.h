@@ -58,6 +58,8 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
 // packed[mb][chunk][part][tap][oc][m][8]: part 0 = hi, 1 = lo; oc < 2*CCG octets of the chunk;
 // m < MP rows of m-block mb.   mode 0: A[o][(tap,c)] = w[o][c][tap]  (w: [Co][Ctot][T])
 //                               mode 1: A[i][(tap,k)] = w[k][i][T-1-tap]  (w: [Ctot][Co][T])
+//                               mode 2 (dcn_fwd4_kernel; T = 1, CCG = 1, "chunk" = k-step j, oc = lane half h):
+//                                       A[o][8 h + c'] = w[o][8 (u / 9) + c'][u % 9], u = 2 j + h  (w: [Co][Ctot][9])
 // One pre-packed weight image: what pack_weights_kernel writes for (w, Co, Ctot, T, MP, CCG, nchunks, nmb, mode).
 // rvsr_pack_weights_batched re-packs a whole table of them in ONE launch (once per optimizer step, realvsr_amd.functional).
 struct PackDesc {
@@ -78,14 +80,18 @@ __device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, b
         r /= T;
         const int chunk = (int)(r % nchunks);
         const int mb = (int)(r / nchunks);
-        const int o = mb * MP + m, cb = (chunk * noct + oc) * 8;
+        const int o = mb * MP + m;
+        const int unit = chunk * 2 + oc;                                   // (mode 2)
+        const int cb = mode == 2 ? 8 * (unit / 9) : (chunk * noct + oc) * 8;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cb + j;
             float x = 0.f;
             if (o < Co && c < Ctot)
-                x = mode == 0 ? w[((size_t)o * Ctot + c) * T + tap] : w[((size_t)c * Co + o) * T + (T - 1 - tap)];
+                x = mode == 0 ? w[((size_t)o * Ctot + c) * T + tap]
+                  : mode == 1 ? w[((size_t)c * Co + o) * T + (T - 1 - tap)]
+                              : w[((size_t)o * Ctot + c) * 9 + unit % 9];
             v[j] = x;
         }
         bf16x8 hi, lo;

@@ -199,10 +199,26 @@ static void fwd2_geom(int Co, int C, int& mt, int& nchunks, int& nmb) {
     nmb = (Co + mt * 32 - 1) / (mt * 32);
 }
 
-size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C) {
+static size_t fwd2_image_bytes(int Co, int C) {
     int mt, nchunks, nmb;
     fwd2_geom(Co, C, mt, nchunks, nmb);
     return (size_t)nmb * nchunks * 2 * 9 * 2 * (mt * 32) * 16;
+}
+// [image of dcn_fwd2 / dcn_fwd3][image of dcn_fwd4 (0 bytes where that kernel does not apply)]
+size_t rvsr_dcn_fwd2_workspace_bytes(int Co, int C) { return fwd2_image_bytes(Co, C) + rvsr_dcn_fwd4_image_bytes(Co, C); }
+static void pack_fwd4_image(const float* weight, int Co, int C, void* out, hipStream_t st, long long* desc) {
+    int mt, nk, nmb;
+    if (!rvsr_dcn_fwd4_geom(Co, C, mt, nk, nmb)) {
+        if (desc) for (int i = 0; i < 10; ++i) desc[i] = 0;
+        return;
+    }
+    const size_t total = (size_t)nmb * nk * 2 * (mt * 32);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, (bf16x8*)out, Co, C, 1, mt * 32, 1,
+                       nk, nmb, 2);
+    if (desc) {
+        desc[0] = (long long)(uintptr_t)weight; desc[1] = (long long)(uintptr_t)out;
+        desc[2] = Co; desc[3] = C; desc[4] = 1; desc[5] = mt * 32; desc[6] = 1; desc[7] = nk; desc[8] = nmb; desc[9] = 2;
+    }
 }
 
 template <int TH, int MT>
@@ -232,6 +248,8 @@ extern "C" size_t rvsr_dcn_pack_weights(const float* weight, int C, int Co, void
         desc[0] = (long long)(uintptr_t)weight; desc[1] = (long long)(uintptr_t)out;
         desc[2] = Co; desc[3] = C; desc[4] = 9; desc[5] = mt * 32; desc[6] = 1; desc[7] = nchunks; desc[8] = nmb; desc[9] = 0;
     }
+    // second image (dcn_fwd4_kernel), second descriptor: desc[10..19], all zero where that kernel does not apply
+    pack_fwd4_image(weight, Co, C, (unsigned char*)out + fwd2_image_bytes(Co, C), (hipStream_t)stream, desc ? desc + 10 : nullptr);
     return need;
 }
 
@@ -243,13 +261,17 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
     const size_t need = rvsr_dcn_fwd2_workspace_bytes(d.Co, d.C);
     if (!workspace || workspace_bytes < need) FAIL(RVSR_ERR_WORKSPACE, "dcn forward: workspace %zu B < %zu B", workspace_bytes, need);
     const size_t total = (size_t)nmb * nchunks * 9 * 2 * (mt * 32);
-    if (!p.prepacked)
+    // the fourth generation's image lies behind the third's; it serves the small-halo case (offsets of a pixel or two)
+    void* wpack4 = rvsr_dcn_fwd4_supported(d) ? (unsigned char*)workspace + fwd2_image_bytes(d.Co, d.C) : nullptr;
+    if (!p.prepacked) {
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, d.Co,
                            d.C, 9, mt * 32, 1, nchunks, nmb, 0);
+        if (wpack4) pack_fwd4_image(p.w, d.Co, d.C, wpack4, st, nullptr);
+    }
     const bf16x8* wp = (const bf16x8*)workspace;
     static const int gen = [] { const char* e = getenv("RVSR_DCN_FWD"); return e ? atoi(e) : 3; }();  // developer A/B switch
     if (gen >= 3) {
-        const int rc = rvsr_launch_dcn_fwd3(p, workspace, mt, st, probe, nprobe, halo_hint);
+        const int rc = rvsr_launch_dcn_fwd3(p, workspace, mt, st, probe, nprobe, halo_hint, wpack4);
         if (rc != RVSR_ERR_UNSUPPORTED) return rc;
     }
     if (mt == 1) return launch_dcn_fwd2<8, 1>(p, wp, st);

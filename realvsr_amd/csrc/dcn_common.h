@@ -109,7 +109,13 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
                          size_t nprobe = 0, int halo_hint = 0);
 // third-generation forward (dcn3_kernels.hip): consumes the weight image rvsr_launch_dcn_fwd2 packs; stride 1, dilation 1
 int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st, const unsigned* probe = nullptr, size_t nprobe = 0,
-                         int halo_hint = 0);
+                         int halo_hint = 0, const void* wpack4 = nullptr);
+// fourth-generation forward (dcn4_kernels.hip): one software pipeline per wave, 5 x 7 px halo; its own weight image ("layout 2",
+// pack_weights_kernel mode 2) which sits BEHIND the third generation's in the workspace / the cached image buffer
+int rvsr_dcn_fwd4_geom(int Co, int C, int& mt, int& nk, int& nmb);
+size_t rvsr_dcn_fwd4_image_bytes(int Co, int C);
+int rvsr_dcn_fwd4_supported(const DcnGeom& d);
+int rvsr_launch_dcn_fwd4(const DcnFwdParams& p, const void* wpack2, hipStream_t st);
 // the three-counter offset statistic both DCN directions select their tile halo from (dcn5_kernels.hip); returns the sample count
 size_t rvsr_launch_dcn_offset_probe(const DcnGeom& d, unsigned* cnt, hipStream_t st);
 size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C);

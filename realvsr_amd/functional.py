@@ -202,7 +202,7 @@ class PackedWeights:
         L = _lib.lib()
         buf = e[0] if e is not None and e[0].numel() >= nbytes and e[0].device == weight.device else \
             torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device)
-        desc = (ctypes.c_longlong * 10)()
+        desc = (ctypes.c_longlong * 20)()   # (the DCN forward keeps two images in one buffer: second descriptor in desc[10:])
         if kind == 'conv':
             got = L.rvsr_conv2d_pack_weights(_p(weight), C_in, Co, k, w_mode, _p(buf), buf.numel(), desc, _stream())
         else:
@@ -210,7 +210,13 @@ class PackedWeights:
         if got == 0:
             return None
         self.stats['packs'] += 1
-        self.entries[key] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc), weight.data_ptr()]
+        self.entries[key] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc[:10]), weight.data_ptr()]
+        if kind != 'conv' and desc[11] != 0:
+            # the image of the fourth-generation DCN forward, behind the first one in the same buffer: its own entry so that
+            # repack() refreshes it as well (same tensor object: the cache hit above returns the whole buffer)
+            self.entries[key + ('image2',)] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc[10:20]), weight.data_ptr()]
+        else:
+            self.entries.pop(key + ('image2',), None)
         self.table = None
         return buf
 
