@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                                    : (unsigned)((((o >> 2) * 2 * H) + 2 * row + ((o >> 1) & 1)) * (2 * W) + 16 * q));
     }
     const bool sec = c0 >= C1;              // (uniform) this workgroup's 64 channels come from the second input
-    int x_row[NXI], x_gx[NXI], x_lds[NXI];
+    int x_row[NXI], x_gx[NXI], x_lds[NXI];   // (x_lds: LDS offset of the item WITHOUT its row term; the row slot is a ring, see below)
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
         const int it_raw = tid + i * WG2_THREADS;
@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         const int c = c0 + cl;
         x_row[i] = row - 1;
         x_gx[i] = 8 * q - 4;
-        x_lds[i] = live ? cl * WG2_XP + row * 80 + q * 16 : -1;
+        x_lds[i] = live ? cl * WG2_XP + q * 16 : -1;
         // relative to a view that starts one row and four pixels BEFORE the image (so that row -1 / column -4 are offset >= 0)
         x_vo[i] = live && c < Ctot ? 4u * (unsigned)(((sec ? c - C1 : c) * H + row) * W + 8 * q) : OOB;
     }
@@ -1431,14 +1431,27 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     // issues one part per k-step of the MFMA phase so the requests trickle out under the matrix work instead of as one
     // burst in front of it (the burst took ~5.5 K cycles to issue: the memory pipeline back-pressures).
     // parts 0-3: X item `part`; parts 4, 5: G item 0, 1; parts 6, 7: nothing.
-    struct TilePos { int b, y0, x0; };
+    // Tile walk.  p.ring: tile ROWS fastest -- consecutive tiles of a workgroup are vertical neighbours, and of the six X rows a
+    // 4-row tile needs (y0 - 1 .. y0 + 4) the first two are the last two of the tile above: they stay in LDS (the row slots form a
+    // ring of six, rotated by four per tile) and only four rows are fetched -- X traffic 1.25x instead of 1.875x the tile's pixels,
+    // 73 instead of 93 KB per tile (the kernel moves as fast as its loads issue, profiles/r03_notes.md).  `fresh`: first tile of a
+    // column (or of the workgroup's range): all six rows are fetched.
+    struct TilePos { int b, y0, x0; bool fresh; };
     auto tile_pos = [&](int tile) {
         TilePos t;
         t.b = tile / (p.nty * p.ntx);
         const int trem = tile - t.b * (p.nty * p.ntx);
-        const int ty = trem / p.ntx;
-        t.y0 = ty * 4;
-        t.x0 = (trem - ty * p.ntx) * 32;
+        if (p.ring) {
+            const int tx = trem / p.nty, ty = trem - tx * p.nty;
+            t.y0 = ty * 4;
+            t.x0 = tx * 32;
+            t.fresh = ty == 0;
+        } else {
+            const int ty = trem / p.ntx;
+            t.y0 = ty * 4;
+            t.x0 = (trem - ty * p.ntx) * 32;
+            t.fresh = true;
+        }
         return t;
     };
     typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -1478,7 +1491,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             for (int i = 0; i < NXI; ++i) {
                 if (part >= 0 && part != i) continue;
                 const int gy = y0 + x_row[i], gx = x0 + x_gx[i];
-                const bool ok = gy >= 0 && gy < H;
+                const bool ok = gy >= 0 && gy < H && (tp.fresh || x_row[i] >= 1);   // (rows y0 - 1, y0 of a non-fresh tile are in LDS already)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const int gxx = gx + 4 * kk;
@@ -1488,7 +1501,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         }
     };
 
-    auto commit = [&]() {
+    auto commit = [&](bool fresh, int rbase) {
 #pragma unroll
         for (int i = 0; i < NGI; ++i) {
             const int ol = g_o[i] - mb * 64;
@@ -1530,7 +1543,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
         }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
-            if (x_lds[i] < 0) continue;
+            if (x_lds[i] < 0 || (!fresh && x_row[i] < 1)) continue;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -1539,8 +1552,11 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             }
             bf16x8 h8, l8;
             split8(v, h8, l8);
-            *reinterpret_cast<bf16x8*>(xs_hi + x_lds[i]) = h8;
-            *reinterpret_cast<bf16x8*>(xs_lo + x_lds[i]) = l8;
+            int slot = x_row[i] + 1 + rbase;          // ring slot of the item's row
+            slot = slot >= 6 ? slot - 6 : slot;
+            const int dst = x_lds[i] + slot * 80;
+            *reinterpret_cast<bf16x8*>(xs_hi + dst) = h8;
+            *reinterpret_cast<bf16x8*>(xs_lo + dst) = l8;
         }
     };
 
@@ -1548,12 +1564,20 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
     const int ntiles = p.B * p.nty * p.ntx;
     const int per = (ntiles + p.P - 1) / p.P;
     const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
-    if (t_begin < t_end) issue_loads(tile_pos(t_begin), -1);
+    TilePos cur_pos = tile_pos(t_begin < t_end ? t_begin : 0);
+    cur_pos.fresh = true;                   // (the first tile of the range has no predecessor in LDS)
+    if (t_begin < t_end) issue_loads(cur_pos, -1);
+    int rbase = 0;                          // ring slot of the tile's row y0 - 1
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const TilePos next_pos = tile_pos(tile + 1 < t_end ? tile + 1 : tile);
+        TilePos next_pos = tile_pos(tile + 1 < t_end ? tile + 1 : tile);
+        if (tile + 1 >= t_end) next_pos.fresh = true;   // (the re-read of the last tile: everything, nothing is committed)
         const int ti = tile - t_begin;
+        rbase = cur_pos.fresh ? 0 : (rbase + 4 >= 6 ? rbase - 2 : rbase + 4);
+        int roff[6];                        // LDS byte offset of tile row r (image row y0 - 1 + r)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) roff[r] = (r + rbase >= 6 ? r + rbase - 6 : r + rbase) * 80;
         if (ti < 6) STAMP(200 + ti * 5);
-        commit();
+        commit(cur_pos.fresh, rbase);
         if (ti < 6) STAMP(201 + ti * 5);
         __syncthreads();
         if (ti < 6) STAMP(202 + ti * 5);
@@ -1575,14 +1599,15 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                 // X octet pair holding stored cols cb .. cb+15 (= image cols x0-4+cb ..); tap dx needs +3+dx
                 const int xbase = (chalf * 32 + lo) * WG2_XP + cb * 2;
                 if (!second) {  // taps (0,0) (0,1) (0,2) (1,0) (1,1)
-                    wg2_row<7>(xs_hi, xs_lo, xbase + (row + 0) * 80, ah, al, acc + 0);
-                    wg2_row<3>(xs_hi, xs_lo, xbase + (row + 1) * 80, ah, al, acc + 3);
+                    wg2_row<7>(xs_hi, xs_lo, xbase + roff[row + 0], ah, al, acc + 0);
+                    wg2_row<3>(xs_hi, xs_lo, xbase + roff[row + 1], ah, al, acc + 3);
                 } else {        // taps (1,2) (2,0) (2,1) (2,2)
-                    wg2_row<4>(xs_hi, xs_lo, xbase + (row + 1) * 80, ah, al, acc + 0);
-                    wg2_row<7>(xs_hi, xs_lo, xbase + (row + 2) * 80, ah, al, acc + 1);
+                    wg2_row<4>(xs_hi, xs_lo, xbase + roff[row + 1], ah, al, acc + 0);
+                    wg2_row<7>(xs_hi, xs_lo, xbase + roff[row + 2], ah, al, acc + 1);
                 }
             }
         }
+        cur_pos = next_pos;
         if (ti < 6) STAMP(204 + ti * 5);
 #ifdef RVSR_TIMELINE
         if (blockIdx.x == 77 && blockIdx.z == 0 && lane == 0 && ti == 3) rvsr_dbg[120 + wave * 10 + 8] = __builtin_amdgcn_s_memtime();

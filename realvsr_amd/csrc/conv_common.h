@@ -79,6 +79,7 @@ struct ConvWgradParams {
     float* part;   // [P][Co][Ctot][T]
     float* bpart;  // [P][Co] or nullptr
     int B, Co, Hout, Wout, ntx, nty, P;
+    int ring;    // conv_wgrad2: walk the tiles column by column and keep the two shared X rows of vertical neighbours in LDS
 };
 
 
