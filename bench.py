@@ -123,7 +123,7 @@ class DcnTimer:
     """HIP events around every fused-DCN forward (and backward) launch on the launching (current) stream."""
 
     def __init__(self):
-        self.events, self.bytes, self.bwd_events = [], 0.0, []
+        self.events, self.bytes, self.bwd_events, self.lds_bytes = [], 0.0, [], 0.0
 
     def install(self):
         from realvsr_amd import functional as RF
@@ -142,6 +142,9 @@ class DcnTimer:
             Wo = (W + 2 * pad - (2 * dil + 1)) // stride + 1
             timer.events.append((s, e))
             timer.bytes += 4.0 * (C * H * W + (216 + Co) * Ho * Wo) * B + 4.0 * Co * C * 9
+            # LDS bytes the kernel's formulation reads per output pixel: 9 taps x 4 corners x C channels x 4 B of x tile (the gather) +
+            # the weight fragments a wave re-reads per (tap, 16-channel chunk): 4 x 1 KB (hi, lo of two 32-row blocks; x2 for Co = 128) per 32 pixels
+            timer.lds_bytes += (9 * 4 * C * 4 + 9 * (C // 16) * 4096 * max(1, Co // 64) / 32.0) * Ho * Wo * B
             return rc
 
         def timed_bwd(*a):
@@ -699,6 +702,17 @@ def main():
                          'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1)),
                          'dcn_bwd_ms_per_step': round(timer.backward_ms() / max(args.steps, 1), 3)},
         }
+        if kms > 0:
+            # what the fused DCN forward is actually bound by (profiles/r04_notes.md): not HBM -- its traffic is 1.12x the algorithmic bytes --
+            # but what one pixel costs on chip.  The LDS side of that: gather + weight-fragment bytes vs 256 B/clk/CU x 256 CUs x 2.4 GHz;
+            # bank conflicts of the per-pixel gather (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.41 at i.i.d. offsets) multiply the LDS
+            # cycles by ~1.7, and the SIMDs' instruction issue (412 instructions per four (wave, tap)s, SQ_ACTIVE_INST_ANY 84 %) is the other half
+            lds_peak = 256 * 256 * 2.4e9 / 1e12
+            lds_ach = timer.lds_bytes / (kms * 1e-3) / 1e12
+            line['roofline_lds'] = {'kernel': 'dcn_fwd3_kernel', 'bound': 'lds', 'achieved': round(lds_ach, 2), 'peak': round(lds_peak, 1), 'unit': 'TB/s',
+                                    'frac': round(lds_ach / lds_peak, 4), 'bytes_per_pixel': round(timer.lds_bytes / max(kbytes, 1) * 4.0 * (args.nf + 216 + args.nf)),
+                                    'note': 'conflict-free LDS bytes of the formulation (corner gather + weight fragments) over the timed launches; '
+                                            'measured bank conflicts multiply the LDS cycles by ~1.7 (profiles/r03_dcn_sq_counters.json)'}
         if allreduce is not None:
             line['allreduce'] = allreduce
         line['roofline_conv'] = conv_roofline(model.netG, B * N, args.nf, H, W, gemm_mode)

@@ -282,12 +282,25 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
                 ah[mt] = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
                 al[mt] = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
             }
+#ifdef RVSR_F3_PRIO   // (scratch variant, tools/build_variant_f3.sh: priority of the wave while it feeds the matrix core)
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bh, acc[mt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bl, acc[mt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
+#ifdef RVSR_F3_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef RVSR_F3_SGB    // (scratch variant: one MFMA per five vector instructions of the next tap's geometry instead of hipcc's clusters)
+#pragma unroll
+            for (int k = 0; k < 3 * MT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 5, 0);
+            }
+#endif
             if (chunk == 1) TSTAMP(40 + tap);
         }
         TSTAMP(5 + 6 * chunk);

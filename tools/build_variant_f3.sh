@@ -1,0 +1,12 @@
+#!/bin/bash
+# Scratch builds of dcn3_kernels.hip with extra -D flags into realvsr_amd/csrc/librealvsr_<name>.so: tools/build_variant_f3.sh <name> <flags...>
+set -e
+NAME="$1"; shift
+T=$(mktemp -d)
+cp realvsr_amd/csrc/*.hip realvsr_amd/csrc/*.h realvsr_amd/csrc/*.inc realvsr_amd/csrc/Makefile "$T"/
+cp realvsr_amd/csrc/*.o "$T"/ 2>/dev/null || true
+rm -f "$T"/dcn3_kernels.o "$T"/librealvsr_hip.so
+make -s -C "$T" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function $*" > /dev/null
+cp "$T/librealvsr_hip.so" realvsr_amd/csrc/librealvsr_$NAME.so
+rm -rf "$T"
+echo built librealvsr_$NAME.so
