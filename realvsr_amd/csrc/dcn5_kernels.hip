@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                 const int r0 = yi - ty0, s0 = xi - tx0;   // tile coordinates of the top-left corner
                 const bool in_tile = (unsigned)r0 < (unsigned)(TR - 1) && (unsigned)s0 < (unsigned)(TC - 1);
                 const bool inside = y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W;
-                const bool far = !in_tile && inside && px_ok;   // beyond the halo: global gather / atomics with the full rule set
+                const bool far = (RVSR_ABL5 & 64) ? false : (!in_tile && inside && px_ok);   // beyond the halo: global gather / atomics with the full rule set
                 const int pos0 = in_tile ? r0 * TC + s0 : 0;
                 float4 a00 = xq[pos0], a01 = xq[pos0 + 1], a10 = xq[pos0 + TC], a11 = xq[pos0 + TC + 1];
                 int i00 = 0, i01 = 0, i10 = 0, i11 = 0;
@@ -481,6 +481,7 @@ static int launch_bwdin5(const DcnBwdIn5Params& p, const bf16x8* wpack, hipStrea
 template <int NK>
 static int launch_bwdin5_halo(const DcnBwdIn5Params& p, const bf16x8* wpack, int halo, hipStream_t st) {
     if (halo <= 2) return launch_bwdin5<NK, 2>(p, wpack, st);
+    if constexpr (NK <= 4) if (halo <= 4) return launch_bwdin5<NK, 4>(p, wpack, st);   // (77 KB: the largest window that still fits twice per CU)
     if (halo <= 5) return launch_bwdin5<NK, 5>(p, wpack, st);
     if (halo <= 8) return launch_bwdin5<NK, 8>(p, wpack, st);
     if constexpr (NK <= 4) return launch_bwdin5<NK, 12>(p, wpack, st);   // (12 px + the 48 KB weight block of NK = 8 exceed 160 KB)
@@ -542,12 +543,24 @@ int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g
     const bool has12 = NK <= 4;
     p.sel.probe = cnt;
     p.sel.thr_ge = p.sel.thr_lt = thr;
-    // R = 2: few components beyond 2.5 px; R = 5: else, few beyond 5.5; R = 8: else, few beyond 8.5 (or no larger tile); R = 12: the rest
-    const int halos[4] = {2, 5, 8, 12}, ge[4] = {-1, 0, 2, 4}, lt[4] = {0, 2, has12 ? 4 : -1, -1};
-    for (int k = 0; k < (has12 ? 4 : 3); ++k) {
-        p.sel.ge = ge[k]; p.sel.lt = lt[k];
-        BWDIN5_DISPATCH(halos[k]);
-        if (rc != RVSR_OK) return rc;
+    // R = 2: few components beyond 2.5 px; R = 4 (round 4: two workgroups per CU like R = 2, where R = 5 fits once): else, few beyond
+    // 3.5 px (hence fewer still beyond its 4.5); R = 5: else, few beyond 5.5; R = 8: else, few beyond 8.5 (or no larger tile); R = 12: the
+    // rest.  The counters are monotone, so the chain is a partition.
+    static const int use4 = [] { const char* e = getenv("RVSR_DCN5_R4"); return e ? atoi(e) : 1; }();   // developer A/B switch
+    if (has12 && use4) {
+        const int halos[5] = {2, 4, 5, 8, 12}, ge[5] = {-1, 0, 1, 2, 4}, lt[5] = {0, 1, 2, 4, -1};
+        for (int k = 0; k < 5; ++k) {
+            p.sel.ge = ge[k]; p.sel.lt = lt[k];
+            BWDIN5_DISPATCH(halos[k]);
+            if (rc != RVSR_OK) return rc;
+        }
+    } else {
+        const int halos[4] = {2, 5, 8, 12}, ge[4] = {-1, 0, 2, 4}, lt[4] = {0, 2, has12 ? 4 : -1, -1};
+        for (int k = 0; k < (has12 ? 4 : 3); ++k) {
+            p.sel.ge = ge[k]; p.sel.lt = lt[k];
+            BWDIN5_DISPATCH(halos[k]);
+            if (rc != RVSR_OK) return rc;
+        }
     }
 #undef BWDIN5_DISPATCH
     return rc;

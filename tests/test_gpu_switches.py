@@ -18,7 +18,7 @@ SETTINGS = ['RVSR_DCN_FWD=2', 'RVSR_DCN_BWD=2', 'RVSR_DCN_BWD=3', 'RVSR_DCN_BWD=
             # profiles/r04_notes.md), in its workgroup shapes; the 4 px / 7 px cases of switch_check.py run its fix-up pass
             'RVSR_DCN_FWD=4', 'RVSR_DCN_FWD=4,RVSR_DCN4_NW=12', 'RVSR_DCN_FWD=4,RVSR_DCN4_PRIO=1',
             # conv_wgrad2 with the X rows of vertical neighbour tiles kept in LDS (a ring of six row slots): measured, no gain, off by default
-            'RVSR_WGRAD_RING=1']
+            'RVSR_WGRAD_RING=1', 'RVSR_DCN5_HALO=4', 'RVSR_DCN5_R4=0']
 
 
 @pytest.mark.parametrize('setting', SETTINGS)
