@@ -115,7 +115,7 @@ def test_bench_self_launches_n_ranks():
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1',
-                          '--height', '32', '--width', '48', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+                          '--height', '32', '--width', '48', '--no-cpu-baseline', '--no-extra'], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     rec = json.loads(line)
@@ -128,7 +128,8 @@ def test_bench_self_launches_n_ranks():
 
 
 def test_bench_line_carries_offset_sweep_and_f32_step():
-    """The driver-timed line (N = 1) reports the large-motion set and the exact-f32 step next to the headline (VERDICT r2 #3)."""
+    """The driver-timed line (N = 1) runs at 1 px mean offsets and reports the raw-init and large-motion steps, the exact-f32 step, the
+    LDS roofline object and the config-3 / config-5 side lines next to the headline (VERDICT r2 #3, r3 #3 / #5)."""
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
@@ -136,9 +137,15 @@ def test_bench_line_carries_offset_sweep_and_f32_step():
                           '--height', '32', '--width', '48', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
-    assert set(rec['offset_sweep']) == {'1px', '3px'}
+    assert abs(rec['config']['offset_abs_mean_px'] - 1.0) < 0.2 and rec['config']['offset_px_requested'] == 1.0
+    assert set(rec['offset_sweep']) == {'raw_init', '3px'}
     for k, v in rec['offset_sweep'].items():
         assert v['ms_per_step'] > 0 and v['dcn_bwd_ms'] > 0 and 0 < v['dcn_fwd_frac'] < 1
-        assert abs(v['offset_abs_mean_px'] - float(k[:-2])) < 0.2 * float(k[:-2])
+        if k == 'raw_init':
+            assert v['offset_abs_mean_px'] < 0.1
+        else:
+            assert abs(v['offset_abs_mean_px'] - float(k[:-2])) < 0.2 * float(k[:-2])
+    assert 0 < rec['roofline_lds']['frac'] < 1 and rec['roofline_lds']['bound'] == 'lds'
+    assert rec['extra']['config3']['ms_per_step'] > 0 and rec['extra']['config5']['ms_per_frame'] > 0 and rec['extra']['config5']['graph_bit_identical']
     assert rec['f32_mode_ms_per_step'] > 0 and rec['roofline']['dcn_bwd_ms_per_step'] > 0
     assert 'allreduce' not in rec
