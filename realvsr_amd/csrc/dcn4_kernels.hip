@@ -13,7 +13,7 @@
 //     basic block per nine k-steps, MFMAs spread between the vector work of OTHER k-steps of the same wave;
 //   * a k-step pairs two UNITS u = 2j, 2j+1 in the two lane halves, a unit = (8-channel chunk u / 9, tap u % 9): the x tile of a
 //     chunk is half as large as the third generation's, which buys a 5 x 7 px halo (rows x columns), a ring of three chunk slots
-//     and a ring of ten k-step weight slices in 160 KB: ONE barrier per chunk, placed where the next chunk's slot and slices are
+//     and a ring of nine k-step weight slices in 160 KB: ONE barrier per chunk, placed where the next chunk's slot and slices are
 //     free anyway, x tile and weights of later k-steps in flight underneath (global loads -> registers -> LDS across a barrier
 //     interval; weights by LDS-DMA);
 //   * no branch in the pipeline: a sample whose 2x2 footprint leaves the tile contributes zero there and sets a flag bit; after
@@ -46,15 +46,6 @@ __device__ __forceinline__ f32x2v blend4v(f32x2v s, f32x2v t, f32x2v a00, f32x2v
     return r;
 }
 
-// Rotating wave priority.  The SIMD arbiter serves the OLDER of two ready waves ("priority, then age"): the first-dispatched waves of
-// a workgroup run at full speed, the later ones on what is left, and at every barrier the former wait 1.5-2 K cycles for the latter
-// (tools/dcn4_timeline.py) while the LDS -- what this kernel is bound by -- idles.  s_setprio takes an immediate, so the group-
-// dependent value is set through a three-way scalar branch inside ONE asm statement (no basic-block split for the compiler).
-__device__ __forceinline__ void fwd4_setprio(int pr /* wave-uniform, 0 .. 2 */) {
-    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 10f\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 11f\n\ts_setprio 2\n\ts_branch 12f\n"
-                 "10:\n\ts_setprio 0\n\ts_branch 12f\n11:\n\ts_setprio 1\n12:" : : "s"(pr) : "scc");
-}
-
 template <int NW, int RY, int RX, int MT>
 struct Fwd4 {
     static constexpr int NT = NW * 64;
@@ -63,7 +54,8 @@ struct Fwd4 {
     static constexpr int XSLOT = 2 * NPOS;     // float4 per chunk slot: [2 quads][NPOS]
     static constexpr int NXS = 3;              // chunk slots
     static constexpr int WSLOT = 4 * MP;       // 16-byte vectors per k-step weight slice: [hi | lo part][lane half][MP]
-    static constexpr int NWS = 10;             // weight slots
+    static constexpr int NWS = 9;              // weight slots: k-step j lives in slot j % 9 -- its index inside the period, a compile-time
+                                               // constant at every place of the pipeline body
     static constexpr int WPI = WSLOT / 64;     // LDS-DMA wave-instructions per weight slice
     static constexpr int NITEM = 2 * TR * TC4; // x staging items (quad, row, group of 4 columns) per chunk
     static constexpr size_t LDS = (size_t)16 * (NXS * XSLOT + NWS * WSLOT) + sizeof(float) * 4 * MP;   // (+ bias of up to 4 m-blocks)
@@ -80,6 +72,25 @@ struct Fwd4Geo {          // sampling geometry of one k-step, per lane
     f32x2v wsd, wt;       // corner weights x mask: (w00, w10), (w01, w11)
 };
 
+// The kernel's own parameter block: only what the pipeline reads, sizes premultiplied on the host.  (DcnFwdParams is 40 dwords; with two
+// tile contexts alive the scalar registers spilled 63-68 values into vector lanes and parts of the uniform arithmetic -- the DMA
+// addressing -- ended up on the vector ALU.)
+struct Fwd4Params {
+    const float* x;        // (B, C, H, W)
+    const float* offset;   // offset planes of batch element 0
+    const float* mask;
+    const float* bias;     // nullable
+    float* out;            // (B, Co, H, W)
+    unsigned long long off_bs, mask_bs;   // elements between batch elements
+    int H, W, C, Co;
+    int ntx, nty, nmb, ntiles;
+    unsigned hw4, HW4;     // bytes per offset / output plane (= 4 H W: stride 1, pad 1), per x plane
+    unsigned mdelta;       // byte distance from the offset planes to the mask planes of the same batch element (one buffer view serves both)
+    int mask_logit, act, swz;
+    float slope;
+    DcnHaloSel sel;
+};
+
 // Per-period context: everything a pipeline stage needs to know about the TILE its k-step belongs to.  Two of them are live --
 // `C` for the period the loop body is in, `N` for the next one (the same tile, or the workgroup's next tile): which one a stage
 // uses is a compile-time property of its position in the body, so a tile boundary costs no selects inside the pipeline.
@@ -87,30 +98,35 @@ struct Fwd4Ctx {
     float Y0, X0;            // (float)(oy - pad), (float)(ox - pad)
     unsigned pix4;           // byte offset of the lane's output pixel inside a plane (0 for lanes without work)
     unsigned x_voff;         // byte offset of the lane's x staging item inside batch element b (bit 31: reads zero)
+    unsigned voff, vmsk;     // RUNNING byte offsets of the lane's next offset / mask request (advanced by every request: no scalar
+                             // plane arithmetic in the pipeline)
+    __amdgpu_buffer_rsrc_t rs;   // offset planes of batch element b (masks: + Fwd4Params::mdelta)
+    unsigned long long wsrc;     // (uniform) address of the weight slices of this period: image of m-block mb, k-step 9 per
     bool px_ok;
     int ty0, tx0;            // image coordinates of tile (0, 0)
     int y0, x0, b, mb;
     int per;                 // period inside the tile
 };
 
-template <int NW, int RY, int RX, int MT>
-__global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack, const int cpg8s, const int ntiles, const int prio_rot, const int dbg) {
+template <int NW, int RY, int RX, int MT, int CPG8S>   // CPG8S = log2(channels per deformable group / 8): 0 or 1
+__global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, const bf16x8* __restrict__ wpack) {
     using F = Fwd4<NW, RY, RX, MT>;
     constexpr int TR = F::TR, TC = F::TC, NPOS = F::NPOS, TC4 = F::TC4, MP = F::MP;
     constexpr int XSLOT = F::XSLOT, WSLOT = F::WSLOT, NWS = F::NWS, WPI = F::WPI;
+    constexpr int PAD = 1;
+    constexpr unsigned XB = (unsigned)(XSLOT * 16);   // bytes per x chunk slot
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* const xs = reinterpret_cast<float4*>(smem_raw);            // [3 slots][2 quads][NPOS], zero outside the image
     bf16x8* const ws = reinterpret_cast<bf16x8*>(xs + F::NXS * XSLOT); // [10 slots][part][half][MP]
     float* const bias_s = reinterpret_cast<float*>(ws + NWS * WSLOT);  // [nmb][MP]
-    const DcnGeom& d = p.d;
-    if (dcn_halo_not_selected(p.sel)) return;   // (uniform) not the kernel the offsets of this call ask for
+    if (dcn_halo_not_selected(d.sel)) return;   // (uniform) not the kernel the offsets of this call ask for
     const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wgrp = wave >> 2;                                        // dispatch-age group of this wave on its SIMD (4 SIMDs)
     const int nper = d.C / 16, nk = 9 * nper;
-    const int nty = (d.Ho + NW - 1) / NW, nmb = (d.Co + MP - 1) / MP;
-    const unsigned HW4 = 4u * (unsigned)(d.H * d.W), hw4 = 4u * (unsigned)(d.Ho * d.Wo);
-    const size_t HW = (size_t)d.H * d.W, hw = (size_t)d.Ho * d.Wo;
+    const int nty = d.nty, nmb = d.nmb, ntiles = d.ntiles;
+    constexpr int cpg8s = CPG8S;
+    const unsigned HW4 = d.HW4, hw4 = d.hw4;
+    const size_t HW = (size_t)d.H * d.W, hw = HW;
     // the tiles of this workgroup: a contiguous range of (batch, m-block, tile row, tile column), XCD by XCD (neighbouring tiles
     // share their halos through the XCD's L2 -- and mostly through this CU's own fetches)
     const unsigned lw = d.swz ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -123,25 +139,38 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
     const int it_q = tid / (TR * TC4), it_rem = tid - it_q * (TR * TC4);
     const int it_r = it_rem / TC4, it_g4 = it_rem - it_r * TC4;
     const int xs_dst = tid < F::NITEM ? it_q * NPOS + it_r * TC + 4 * it_g4 : -1;
-    const unsigned hi2 = hi ? 2u * hw4 : 0u, hi1 = hi ? hw4 : 0u;   // the hi lane half is one tap further: + 2 offset planes / + 1 mask plane
+    const unsigned hw4x2 = 2u * hw4, hw4x4 = 4u * hw4;
+    const unsigned hi2 = hi ? hw4x2 : 0u, hi1 = hi ? hw4 : 0u;   // the hi lane half is one tap further: + 2 offset planes / + 1 mask plane
 
+    // running request offsets at k-step 0 of period c.per: the lane's unit is u = 18 per + hi = (chunk 2 per, tap hi); unit (chunk, t)
+    // reads offset planes 18 (chunk >> CPG8S) + 2 t (+1) and mask plane 9 (chunk >> CPG8S) + t
+    auto start_period = [&](Fwd4Ctx& c) {
+        const unsigned pm = (unsigned)(CPG8S == 0 ? 18 : 9) * (unsigned)c.per * hw4;   // (uniform)
+        c.voff = c.pix4 + hi2 + 2u * pm;
+        c.vmsk = c.pix4 + hi1 + pm;
+        const unsigned long long a = (unsigned long long)(uintptr_t)(wpack + ((size_t)c.mb * nk + 9 * c.per) * WSLOT);
+        c.wsrc = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32) |
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    };
     auto make_ctx = [&](Fwd4Ctx& c, int tile, int per) {
         int t = tile;
         const int tx = t % d.ntx; t /= d.ntx;
         const int ty = t % nty; t /= nty;
         c.mb = t % nmb; c.b = t / nmb;
         c.x0 = tx * 32; c.y0 = ty * NW;
-        c.ty0 = c.y0 - d.pad - RY; c.tx0 = c.x0 - d.pad - RX;
+        c.ty0 = c.y0 - PAD - RY; c.tx0 = c.x0 - PAD - RX;
         const int oy = c.y0 + wave, ox = c.x0 + lo;
-        c.px_ok = oy < d.Ho && ox < d.Wo;
-        c.pix4 = c.px_ok ? 4u * (unsigned)(oy * d.Wo + ox) : 0u;   // lanes without work read pixel 0 (loads stay unconditional)
+        c.px_ok = oy < d.H && ox < d.W;
+        c.pix4 = c.px_ok ? 4u * (unsigned)(oy * d.W + ox) : 0u;   // lanes without work read pixel 0 (loads stay unconditional)
         // Sample positions are formed in IMAGE coordinates exactly as the reference does (float(h_in + i) + offset,
         // kernel.cu:594-616) so that floor() and the fractional weights round identically
-        c.Y0 = (float)(oy - d.pad); c.X0 = (float)(ox - d.pad);
+        c.Y0 = (float)(oy - PAD); c.X0 = (float)(ox - PAD);
         const int gy = c.ty0 + it_r, gx = c.tx0 + 4 * it_g4;
         const bool ok = tid < F::NITEM && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
         c.x_voff = ok ? 4u * (unsigned)(gy * d.W + gx) + (unsigned)(4 * it_q) * HW4 : 0x80000000u;
         c.per = per;
+        c.rs = buf_view(d.offset + (size_t)c.b * d.off_bs);
+        start_period(c);
     };
 
     // ---- staging: global -> registers -> LDS, one chunk (8 channels) at a time
@@ -152,9 +181,9 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
         for (int e = 0; e < 4; ++e)
             xv[e] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(x2g_rs, (int)c.x_voff, (int)((unsigned)(8 * chunk + e) * HW4), 0));
     };
-    auto x_write2 = [&](const f32x4v (&xv)[4], int slot, int half) {   // two of the item's four positions
+    auto x_write2 = [&](const f32x4v (&xv)[4], unsigned xb, int half) {   // two of the item's four positions; xb = slot byte address
         if (xs_dst >= 0) {
-            float4* dst = xs + slot * XSLOT + xs_dst;
+            float4* dst = reinterpret_cast<float4*>(smem_raw + xb) + xs_dst;
             if (half == 0) {
                 dst[0] = make_float4(xv[0].x, xv[1].x, xv[2].x, xv[3].x);
                 dst[1] = make_float4(xv[0].y, xv[1].y, xv[2].y, xv[3].y);
@@ -164,58 +193,45 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
             }
         }
     };
-    // weight slices of `nj` k-steps starting `ahead` k-steps after the current one (slot `slot_now`, k-step `j_now` of m-block mb_now;
-    // past the tile's last k-step: the first ones of the next tile's m-block) -> their ring slots, by LDS-DMA
+    // Weight slices by LDS-DMA, two k-steps per call: waves 0 .. WPI-1 move the 1 KB pieces of k-step jl of c's period, waves WPI ..
+    // 2 WPI - 1 those of k-step jl + 1 (`both` = false: only the first).  k-step j lives in slot j % 9, so with jl a compile-time
+    // constant everything but the wave's own piece offset is an immediate: one vector add (source offset), one scalar add (M0).
+    // Inline assembly on purpose: next to a __builtin_amdgcn_global_load_lds in flight hipcc waits vmcnt(0) at the use of EVERY
+    // ordinary load (here: the offset / mask requests of each k-step), which drains the requests of the following k-steps once per
+    // iteration.  The DMA has no register destination, so hiding it from the compiler's counters is safe (its waits can only
+    // become conservative); completion is waited for explicitly before the next barrier event.
     const unsigned ws_base = (unsigned)(F::NXS * XSLOT * 16);   // LDS byte address of the weight ring (the dynamic LDS segment starts at 0)
-    auto w_issue = [&](int j_now, int slot_now, int ahead, int nj, int mb_now, int mb_next) {
-#pragma unroll
-        for (int k = 0; k < (5 * WPI + NW - 1) / NW; ++k) {
-            const int idx = wave + k * NW;               // (uniform)
-            if (idx < nj * WPI) {
-                const int dj = ahead + idx / WPI, sub = idx % WPI;
-                int j = j_now + dj, mbj = mb_now;
-                if (j >= nk) { j -= nk; mbj = mb_next; }
-                int slot = slot_now + dj;
-                while (slot >= NWS) slot -= NWS;
-                // Inline assembly on purpose: next to a __builtin_amdgcn_global_load_lds in flight hipcc waits vmcnt(0) at the use of EVERY
-                // ordinary load (here: the offset / mask requests of each k-step), which drains the requests of the following
-                // k-steps once per iteration.  The DMA has no register destination, so hiding it from the compiler's counters is safe
-                // (its waits can only become conservative); completion is waited for explicitly before the next barrier event.
-                const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ws_base + (unsigned)((slot * WSLOT + sub * 64) * 16)));
-                const bf16x8* src = wpack + ((size_t)mbj * nk + j) * WSLOT + sub * 64 + lane;
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-            }
+    const int wq = wave / WPI;                                  // (uniform) which k-step of a pair this wave moves; >= 2: none
+    const unsigned wconst = (unsigned)__builtin_amdgcn_readfirstlane((wq * WSLOT + (wave % WPI) * 64) * 16);
+    const unsigned wv = 16u * (unsigned)lane + wconst;
+    auto w_pair = [&](const Fwd4Ctx& c, int jl, bool both) {
+        if (wq < (both ? 2 : 1)) {   // (uniform)
+            const unsigned voff = wv + (unsigned)(jl * WSLOT * 16);
+            const unsigned m0v = ws_base + (unsigned)(jl * WSLOT * 16) + wconst;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(c.wsrc), "s"(m0v) : "memory", "m0");
         }
     };
 
     // ---- offset / mask requests of k-step jj of c's period: three dword loads per lane
     struct Req { float dy, dx, m; };
-    auto request = [&](Req& q, const Fwd4Ctx& c, int jj) {
-        const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)c.b * d.off_bs);
-        const __amdgpu_buffer_rsrc_t msk_rs = buf_view(d.mask + (size_t)c.b * d.mask_bs);
-        // (uniform scalar arithmetic) deformable groups of the period's two chunks; unit u reads offset channels 18 g + 2 t (+1)
-        // and mask channel 9 g + t
-        const int g0 = (2 * c.per) >> cpg8s, g1 = (2 * c.per + 1) >> cpg8s;
-        if (jj != 4) {
-            const int ul = 2 * jj, g = f4_cl(ul) ? g1 : g0, t = f4_tap(ul);
-            const unsigned so = (unsigned)(18 * g + 2 * t) * hw4, sm = (unsigned)(9 * g + t) * hw4;
-            q.dy = buf_load(off_rs, c.pix4 + hi2, so);
-            q.dx = buf_load(off_rs, c.pix4 + hi2, so + hw4);
-            q.m = buf_load(msk_rs, c.pix4 + hi1, sm);
-        } else {
-            // units 8 (chunk 0, tap 8) and 9 (chunk 1, tap 0): their planes are 2 apart only when the chunks are different groups
-            const int cl = 18 * g0 + 16, ch = 18 * g1, base = cl < ch ? cl : ch;
-            const int ml = 9 * g0 + 8, mh = 9 * g1, mbase = ml < mh ? ml : mh;
-            const unsigned vo = c.pix4 + (unsigned)(hi ? ch - base : cl - base) * hw4, vm = c.pix4 + (unsigned)(hi ? mh - mbase : ml - mbase) * hw4;
-            q.dy = buf_load(off_rs, vo, (unsigned)base * hw4);
-            q.dx = buf_load(off_rs, vo, (unsigned)(base + 1) * hw4);
-            q.m = buf_load(msk_rs, vm, (unsigned)mbase * hw4);
+    auto request = [&](Req& q, Fwd4Ctx& c, int jj) {
+        q.dy = buf_load(c.rs, c.voff, 0u);
+        q.dx = buf_load(c.rs, c.voff, hw4);
+        q.m = buf_load(c.rs, c.vmsk, d.mdelta);
+        // advance to the lane's next unit (u + 2): four offset planes / two mask planes further, except where the step crosses from
+        // the period's first chunk into its second and both are the same deformable group (CPG8S == 1: taps 7, 8 -> 0, 1: -14 / -7)
+        const int ul0 = 2 * jj, ul1 = 2 * jj + 1;
+        const bool back0 = CPG8S == 1 && ul0 < 9 && ul0 + 2 >= 9, back1 = CPG8S == 1 && ul1 < 9 && ul1 + 2 >= 9;
+        if (!back0 && !back1) { c.voff += hw4x4; c.vmsk += hw4x2; }
+        else {
+            const unsigned bo = 0u - 14u * hw4, bm = 0u - 7u * hw4;
+            const bool back = hi ? back1 : back0;
+            c.voff += back ? bo : hw4x4;
+            c.vmsk += back ? bm : hw4x2;
         }
     };
-    // ---- sampling geometry of that k-step from its offsets; `s0` = x slot of the period's first chunk
-    auto geometry = [&](Fwd4Geo& G, unsigned& flags, const Req& q, const Fwd4Ctx& c, int jj, int s0) {
+    // ---- sampling geometry of that k-step from its offsets; xb0 / xb1 = (uniform) LDS byte addresses of the period's two chunk slots
+    auto geometry = [&](Fwd4Geo& G, unsigned& flags, const Req& q, const Fwd4Ctx& c, int jj, unsigned xb0, unsigned xb1) {
         const int ul0 = 2 * jj, ul1 = 2 * jj + 1;
         const int t0 = f4_tap(ul0), t1 = f4_tap(ul1);
         const int ky0 = t0 / 3, kx0 = t0 % 3, ky1 = t1 / 3, kx1 = t1 % 3;
@@ -237,8 +253,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
         const unsigned pos_raw = __umul24((unsigned)r0, (unsigned)TC) + (unsigned)c0;
         const unsigned pos = in_tile ? pos_raw : 0u;
         // chunk slot of this lane's unit (uniform except at jj == 4, where the lane halves are in different chunks)
-        const int sl0 = s0 + f4_cl(ul0), sl1 = s0 + f4_cl(ul1);
-        const unsigned b0 = (unsigned)((sl0 >= 3 ? sl0 - 3 : sl0) * XSLOT * 16), b1 = (unsigned)((sl1 >= 3 ? sl1 - 3 : sl1) * XSLOT * 16);
+        const unsigned b0 = f4_cl(ul0) ? xb1 : xb0, b1 = f4_cl(ul1) ? xb1 : xb0;
         G.addr = pos * 16u + (f4_cl(ul0) == f4_cl(ul1) ? b0 : (hi ? b1 : b0));
         const float wy1 = ly * m;
         const f32x2v wy = {m - wy1, wy1};
@@ -298,11 +313,10 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
         f32x4v xw[4];
         x_load(xv, C, 0);
         x_load(xw, C, 1);
-        w_issue(0, 0, 0, 5, C.mb, C.mb);
-        w_issue(0, 0, 5, 2, C.mb, C.mb);
-        for (int o = tid; o < nmb * MP; o += NW * 64) bias_s[o] = (p.bias != nullptr && o < d.Co) ? p.bias[o] : 0.f;
-        x_write2(xv, 0, 0); x_write2(xv, 0, 1);
-        x_write2(xw, 1, 0); x_write2(xw, 1, 1);
+        w_pair(C, 0, true); w_pair(C, 2, true); w_pair(C, 4, true); w_pair(C, 6, false);   // k-steps 0 .. 6
+        for (int o = tid; o < nmb * MP; o += NW * 64) bias_s[o] = (d.bias != nullptr && o < d.Co) ? d.bias[o] : 0.f;
+        x_write2(xv, 0u, 0); x_write2(xv, 0u, 1);
+        x_write2(xw, XB, 0); x_write2(xw, XB, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the weight DMAs of this wave have landed)
     __syncthreads();
@@ -313,25 +327,25 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
     unsigned flC = 0, flN = 0;           // out-of-tile flags of the current / the next period
     float4 cq[8];
     bf16x8 bhP, blP;                     // B fragments of k-step i-1
-    int s0 = 0;                          // x slot of the period's first chunk
+    // (uniform) LDS byte addresses of the three x chunk slots in ring order: the period's chunks are in xa, xb; the next period's go
+    // to xc and -- once the period's first chunk is used up -- xa
+    unsigned xa = 0u, xb = XB, xc = 2u * XB;
     {   // iteration 0 of the first period, without a predecessor to multiply
         Fwd4Geo g0;
-        geometry(g0, flC, rq0, C, 0, 0);
+        geometry(g0, flC, rq0, C, 0, 0u, XB);
         corners(cq, g0);
-        geometry(gC, flC, rq1, C, 1, 0);
+        geometry(gC, flC, rq1, C, 1, 0u, XB);
         float v[8];
         blend(v, cq, g0);
         corners(cq, gC);
         split8(v, bhP, blP);
-        geometry(gN, flC, rq2, C, 2, 0);
+        geometry(gN, flC, rq2, C, 2, 0u, XB);
     }
-    int wslP = 0, wslC = 1;              // weight slots of k-steps i-1 and i
 
     // =============================================================================== the pipeline
     // One body = iterations 1 .. 8 of period C.per and iteration 0 of the next period ("jj == 9"): a tile's last product (k-step 8
     // of its last period) is multiplied in that final iteration, so the tile's epilogue sits at a body boundary.
     for (;;) {
-        const int s0n = s0 + 2 >= 3 ? s0 - 1 : s0 + 2;           // (s0 + 2) % 3: x slot of the NEXT period's first chunk
         const int jbase = 9 * C.per;
 #ifdef RVSR_TIMELINE_DCN4
         const bool tl = tile == t_begin + 1 && C.per < 4;     // the workgroup's second tile
@@ -340,12 +354,6 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
 #endif
 #pragma unroll
         for (int jj = 1; jj <= 9; ++jj) {
-            if (prio_rot) {   // (uniform, kernel argument)
-                constexpr int NG = NW / 4;          // waves per SIMD = age groups
-                int pr = jj % NG + wgrp;             // the group that leads changes every iteration
-                pr = pr >= NG ? pr - NG : pr;
-                fwd4_setprio(pr);
-            }
             // ---- V1(i): four-corner blend of k-step i
             float v[8];
             blend(v, cq, gC);
@@ -355,38 +363,35 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
                 // requests (four k-steps) were issued after them, so "at most 9 operations outstanding" implies it -- without draining
                 // the requests of the next three k-steps (vmcnt(0) exposes one HBM round trip per event: measured 2-5 K cycles).
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                if (!(dbg & 8)) __syncthreads();
-                // weight slices of the k-steps that follow the NEXT event
-                if (!(dbg & 1)) { if (jj == 3) w_issue(jbase + 3, wslC, 4, 4, C.mb, N.mb); else w_issue(jbase + 8, wslC, 3, 5, C.mb, N.mb); }
+                __syncthreads();
+                // weight slices of the k-steps that follow the NEXT event: 7, 8 of this period and 0, 1 of the next / 2 .. 6 of the next
+                if (jj == 3) { w_pair(C, 7, true); w_pair(N, 0, true); }
+                else { w_pair(N, 2, true); w_pair(N, 4, true); w_pair(N, 6, false); }
             }
             // ---- staging, trickled over the iterations after an event so that the eight waves' LDS stores and 16-byte loads do not
-            // pile up behind the barrier: the registers hold the next period's first chunk at jj == 3 (slot s0 + 2), its second
-            // chunk at jj == 8 (slot s0 + 3 = s0); they are refilled two iterations after their last store
-            if (!(dbg & 2)) {
-                if (jj == 3) x_write2(xv, s0n, 0);
-                if (jj == 4) x_write2(xv, s0n, 1);
-                if (jj == 8) x_write2(xv, s0, 0);
-                if (jj == 9) x_write2(xv, s0, 1);
-            }
-            if (jj == 5 && !(dbg & 4)) x_load(xv, N, 1);
+            // pile up behind the barrier: the registers hold the next period's first chunk at jj == 3 (slot xc), its second
+            // chunk at jj == 8 (slot xa); they are refilled two iterations after their last store
+            if (jj == 3) x_write2(xv, xc, 0);
+            if (jj == 4) x_write2(xv, xc, 1);
+            if (jj == 8) x_write2(xv, xa, 0);
+            if (jj == 9) x_write2(xv, xa, 1);
+            if (jj == 5) x_load(xv, N, 1);
             // ---- L(i+1): corner reads of k-step i+1
             corners(cq, gN);
             // ---- V2(i): bf16 hi / lo split of k-step i
             bf16x8 bh, bl;
             split8(v, bh, bl);
             // ---- M(i-1): the matrix core runs k-step i-1
-            mma(wslP, bhP, blP);
+            mma(jj - 1, bhP, blP);
             // ---- G(i+2): geometry of k-step i+2, requests of k-step i+5
             {
                 const int j2 = jj + 2, j5 = jj + 5;
-                if (j2 < 9) geometry(gNN, flC, rqa, C, j2, s0); else geometry(gNN, flN, rqa, N, j2 - 9, s0n);
+                if (j2 < 9) geometry(gNN, flC, rqa, C, j2, xa, xb); else geometry(gNN, flN, rqa, N, j2 - 9, xc, xa);
                 rqa = rqb; rqb = rqc;
                 if (j5 < 9) request(rqc, C, j5); else request(rqc, N, j5 - 9);
             }
             gC = gN; gN = gNN;
             bhP = bh; blP = bl;
-            wslP = wslC;
-            wslC = wslC + 1 == NWS ? 0 : wslC + 1;
 #ifdef RVSR_TIMELINE_DCN4
             if (tl) TSTAMP4(tb + jj);
 #endif
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
                     const float dy = ob[0], dx = ob[hw];
                     float m = d.mask[(size_t)C.b * d.mask_bs + (size_t)(9 * g + t) * hw + (C.pix4 >> 2)];
                     if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
-                    const float y = (float)(oy - d.pad + t / 3) + dy, x = (float)(ox - d.pad + t % 3) + dx;
+                    const float y = (float)(oy - PAD + t / 3) + dy, x = (float)(ox - PAD + t % 3) + dx;
                     // the reference's rules spelled out (image coordinates; kernel.cu:467-497,618)
                     if (y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W) {
                         const float gy_ = floorf(y), gx_ = floorf(x);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
             }
         }
         flC = flN; flN = 0;
-        s0 = s0n;
+        { const unsigned t = xa; xa = xc; xc = xb; xb = t; }   // (xa, xb, xc) <- (xc, xa, xb)
 #ifdef RVSR_TIMELINE_DCN4
         if (tl) TSTAMP4(tb + 10);
 #endif
@@ -450,16 +455,16 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
         if (tile_done) {
             // ========================================================================== epilogue of the finished tile
             const int oy = C.y0 + wave, ox = C.x0 + lo;
-            const __amdgpu_buffer_rsrc_t out_rs = buf_view(p.out + (size_t)C.b * d.Co * hw);
+            const __amdgpu_buffer_rsrc_t out_rs = buf_view(d.out + (size_t)C.b * d.Co * hw);
             const float* bias_m = bias_s + C.mb * MP;
-            if (oy < d.Ho) {
-                const float neg = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : p.slope);
-                if ((d.Wo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0) {   // (uniform)
+            if (oy < d.H) {
+                const float neg = d.act == 0 ? 1.f : (d.act == 1 ? 0.f : d.slope);
+                if ((((uintptr_t)d.out) & 15) == 0) {   // (uniform; W % 4 == 0 is a launch condition)
                     // 16-byte stores: a 4x4 transpose inside every quad of lanes turns "lane = pixel, 4 registers = 4 consecutive
                     // channels" into "lane = channel, 4 consecutive pixels"
                     const int j = lo & 3, col4 = C.x0 + (lo & ~3);
-                    const bool col_ok = col4 < d.Wo;   // Wo % 4 == 0: the float4 is entirely inside or outside
-                    const unsigned lane_off = 4u * ((unsigned)(4 * hi + j) * (unsigned)hw + (unsigned)oy * d.Wo + col4);
+                    const bool col_ok = col4 < d.W;   // W % 4 == 0: the float4 is entirely inside or outside
+                    const unsigned lane_off = 4u * ((unsigned)(4 * hi + j) * (unsigned)hw + (unsigned)oy * d.W + col4);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -477,17 +482,17 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
                         }
                     }
                 } else {
-                    const size_t pix = (size_t)oy * d.Wo + ox;
+                    const size_t pix = (size_t)oy * d.W + ox;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ol = mt * 32 + drow(r, hi);
                             const int o = C.mb * MP + ol;
-                            const bool ok = ox < d.Wo && o < d.Co;
+                            const bool ok = ox < d.W && o < d.Co;
                             float v = acc[mt][r] + bias_m[ol];
                             v = v > 0.f ? v : v * neg;
-                            if (ok) p.out[((size_t)C.b * d.Co + o) * hw + pix] = v;
+                            if (ok) d.out[((size_t)C.b * d.Co + o) * hw + pix] = v;
                         }
                     }
                 }
@@ -503,10 +508,10 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const DcnFwdParams p,
         // ---- contexts of the next body: C <- N; N <- the period after it (the same tile, the next tile, or -- behind the last
         // tile -- the same context again: its look-ahead results are never used)
         C = N;
-        if (C.per + 1 < nper) { N = C; N.per = C.per + 1; }
+        if (C.per + 1 < nper) { N = C; N.per = C.per + 1; start_period(N); }
         else make_ctx(N, tile + 1 < t_end ? tile + 1 : tile, 0);
         // the staging registers were last stored from in iteration "jj == 9": refill them with the second period ahead's first chunk
-        if (!(dbg & 4)) x_load(xv, N, 0);
+        x_load(xv, N, 0);
     }
     TSTAMP4(58);
 }
@@ -527,16 +532,26 @@ size_t rvsr_dcn_fwd4_image_bytes(int Co, int C) {
     return (size_t)nmb * nk * 4 * (mt * 32) * 16;
 }
 
-template <int NW, int RY, int RX, int MT>
-static int launch_dcn_fwd4(const DcnFwdParams& p, const bf16x8* wpack, int cpg8s, hipStream_t st) {
+template <int NW, int RY, int RX, int MT, int CPG8S>
+static int launch_dcn_fwd4(const DcnFwdParams& p, const bf16x8* wpack, hipStream_t st) {
     using F = Fwd4<NW, RY, RX, MT>;
-    auto k = dcn_fwd4_kernel<NW, RY, RX, MT>;
+    auto k = dcn_fwd4_kernel<NW, RY, RX, MT, CPG8S>;
     if (set_lds(k, F::LDS)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd4: cannot reserve %zu B of LDS", F::LDS);
     const DcnGeom& d = p.d;
     const int nmb = (d.Co + MT * 32 - 1) / (MT * 32);
     if (nmb > 4) return RVSR_ERR_UNSUPPORTED;
-    const long long ntiles = (long long)d.ntx * ((d.Ho + NW - 1) / NW) * nmb * d.B;
+    const int nty = (d.Ho + NW - 1) / NW;
+    const long long ntiles = (long long)d.ntx * nty * nmb * d.B;
     if (ntiles >= (1ll << 30)) return RVSR_ERR_UNSUPPORTED;
+    Fwd4Params q;
+    q.x = d.x; q.offset = d.offset; q.mask = d.mask; q.bias = p.bias; q.out = p.out;
+    q.off_bs = d.off_bs; q.mask_bs = d.mask_bs;
+    q.H = d.H; q.W = d.W; q.C = d.C; q.Co = d.Co;
+    q.ntx = d.ntx; q.nty = nty; q.nmb = nmb; q.ntiles = (int)ntiles;
+    q.hw4 = 4u * (unsigned)(d.H * d.W); q.HW4 = q.hw4;
+    q.mdelta = (unsigned)((d.mask - d.offset) * (ptrdiff_t)sizeof(float));
+    q.mask_logit = d.mask_logit; q.act = p.act; q.swz = d.swz; q.slope = p.slope;
+    q.sel = p.sel;
     // persistent: one workgroup per CU walks a contiguous range of tiles (the pipeline runs across tile boundaries)
     static thread_local int ncu[16] = {0};
     int dev = 0;
@@ -547,9 +562,7 @@ static int launch_dcn_fwd4(const DcnFwdParams& p, const bf16x8* wpack, int cpg8s
         ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const unsigned nwg = (unsigned)(ntiles < ncu[dev] ? ntiles : ncu[dev]);
-    static const int prio = [] { const char* e = getenv("RVSR_DCN4_PRIO"); return e ? atoi(e) : 0; }();   // developer A/B switch
-    static const int dbg = [] { const char* e = getenv("RVSR_DCN4_DBG"); return e ? atoi(e) : 0; }();     // timing ablations (WRONG results): 1 no weight DMA, 2 no x stores, 4 no x loads, 8 no barriers
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), F::LDS, st, p, wpack, cpg8s, (int)ntiles, prio, dbg);
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), F::LDS, st, q, wpack);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd4 launch: %s", hipGetErrorString(e));
     return RVSR_OK;
@@ -562,8 +575,11 @@ int rvsr_dcn_fwd4_supported(const DcnGeom& d) {
     int mt, nk, nmb;
     if (!rvsr_dcn_fwd4_geom(d.Co, d.C, mt, nk, nmb)) return 0;
     if (d.stride != 1 || d.dil != 1 || d.pad != 1 || d.cpg % 8 != 0) return 0;
-    const int cpg8 = d.cpg / 8;
-    if (cpg8 & (cpg8 - 1)) return 0;
+    if (d.cpg != 8 && d.cpg != 16) return 0;
+    // one buffer view serves the offset and the mask planes of a batch element (the fused offset/mask tensor, or two tensors that
+    // happen to lie within 4 GB of each other)
+    if (d.mask < d.offset || d.off_bs != d.mask_bs) return 0;
+    if ((size_t)(d.mask - d.offset) * sizeof(float) + (size_t)(d.C / d.cpg) * 9 * d.H * d.W * sizeof(float) >= ((size_t)1 << 32)) return 0;
     if (d.W % 4 != 0 || (((uintptr_t)d.x) & 15) != 0 || d.H != d.Ho || d.W != d.Wo) return 0;
     // 32-bit byte offsets into one batch element's planes; x through a 2 GB view
     const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)(d.C > d.Co ? d.C : d.Co) ? (size_t)(d.C / d.cpg) * 18 : (size_t)(d.C > d.Co ? d.C : d.Co);
@@ -575,11 +591,7 @@ int rvsr_launch_dcn_fwd4(const DcnFwdParams& p, const void* wpack2, hipStream_t 
     const DcnGeom& d = p.d;
     int mt, nk, nmb;
     if (!rvsr_dcn_fwd4_supported(d) || !rvsr_dcn_fwd4_geom(d.Co, d.C, mt, nk, nmb)) return RVSR_ERR_UNSUPPORTED;
-    int cpg8s = 0;
-    while ((8 << cpg8s) < d.cpg) ++cpg8s;
     const bf16x8* wp = (const bf16x8*)wpack2;
-    static const int nw = [] { const char* e = getenv("RVSR_DCN4_NW"); return e ? atoi(e) : 8; }();   // developer A/B switch
-    if (mt == 1) return launch_dcn_fwd4<8, 5, 7, 1>(p, wp, cpg8s, st);
-    if (nw == 12) return launch_dcn_fwd4<12, 5, 7, 2>(p, wp, cpg8s, st);   // (3 waves per SIMD: 168 registers, spills)
-    return launch_dcn_fwd4<8, 5, 7, 2>(p, wp, cpg8s, st);
+    if (d.cpg == 8) return mt == 1 ? launch_dcn_fwd4<8, 5, 7, 1, 0>(p, wp, st) : launch_dcn_fwd4<8, 5, 7, 2, 0>(p, wp, st);
+    return mt == 1 ? launch_dcn_fwd4<8, 5, 7, 1, 1>(p, wp, st) : launch_dcn_fwd4<8, 5, 7, 2, 1>(p, wp, st);
 }

@@ -16,7 +16,7 @@ SETTINGS = ['RVSR_DCN_FWD=2', 'RVSR_DCN_BWD=2', 'RVSR_DCN_BWD=3', 'RVSR_DCN_BWD=
             'RVSR_DCN3_HALO=11', 'RVSR_CONV_WIDE=0', 'RVSR_PACK_CACHE=0', 'RVSR_CONV_FWD6=1', 'RVSR_FUSE_GRAD_MASK=0',
             # the fourth-generation DCN forward (dcn4_kernels.hip: persistent, software-pipelined; measured, not the default -- see
             # profiles/r04_notes.md), in its workgroup shapes; the 4 px / 7 px cases of switch_check.py run its fix-up pass
-            'RVSR_DCN_FWD=4', 'RVSR_DCN_FWD=4,RVSR_DCN4_NW=12', 'RVSR_DCN_FWD=4,RVSR_DCN4_PRIO=1',
+            'RVSR_DCN_FWD=4',
             # conv_wgrad2 with the X rows of vertical neighbour tiles kept in LDS (a ring of six row slots): measured, no gain, off by default
             'RVSR_WGRAD_RING=1', 'RVSR_DCN5_HALO=4', 'RVSR_DCN5_R4=0']
 

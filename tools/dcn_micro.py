@@ -18,12 +18,19 @@ ap.add_argument('--H', type=int, default=180)
 ap.add_argument('--W', type=int, default=320)
 ap.add_argument('--ostd', type=float, default=1.0, help='std of the offsets in pixels')
 ap.add_argument('--fwd-only', action='store_true')
+ap.add_argument('--smooth', type=int, default=0, help='offset field = noise on a grid S x coarser, bilinearly upsampled and rescaled to --ostd '
+                '(0: i.i.d. per pixel and tap, the harshest case for the LDS gathers)')
 ap.add_argument('--coherent', type=float, default=None, help='all offsets equal to this value (no sub-pixel sign jitter between neighbouring pixels)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.B, a.C, a.H, a.W, generator=g).to(dev).requires_grad_(True)
 om = torch.randn(a.B, 216, a.H, a.W, generator=g)
+if a.smooth > 1:
+    import torch.nn.functional as F
+    coarse = torch.randn(a.B, 144, (a.H + a.smooth - 1) // a.smooth + 1, (a.W + a.smooth - 1) // a.smooth + 1, generator=g)
+    fine = F.interpolate(coarse, size=(a.H, a.W), mode='bilinear', align_corners=True)
+    om[:, :144] = fine / fine.std()
 om[:, :144] *= a.ostd
 if a.coherent is not None:
     om[:, :144] = a.coherent
