@@ -209,8 +209,8 @@ def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
         torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
     flop = 2.0 * frames * H * W * nf * nf * 9
-    passes = 3 if gemm_mode == 'bf16x3' else 1
-    peak = MFMA_BF16_PEAK_TFLOPS if gemm_mode == 'bf16x3' else MFMA_F32_PEAK_TFLOPS
+    passes = GEMM_PASSES[gemm_mode]
+    peak = MFMA_F32_PEAK_TFLOPS if gemm_mode == 'f32' else MFMA_BF16_PEAK_TFLOPS
     ach = passes * flop / (ms * 1e-3) / 1e12
     return {'kernel': 'conv_fwd5_kernel (+ its weight pre-pack): 3x3 %d->%d + ReLU on %d frames of %dx%d' % (nf, nf, frames, H, W),
             'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
@@ -292,18 +292,37 @@ def offset_sweep(model, x, first_step, native, pxs=(3.0,), steps=3):
     return out
 
 
-def f32_mode_step(model, first_step, steps=2):
-    """The same step in the exact-f32 GEMM mode (v_mfma_f32_32x32x2_f32 everywhere), 2 untimed + `steps` timed."""
+def gemm_mode_step(model, first_step, mode, steps=2):
+    """The same step in another GEMM mode ('f32': v_mfma_f32_32x32x2_f32 everywhere; 'bf16x2' / 'bf16': the reduced-term speed modes),
+    2 untimed + `steps` timed; parameters and optimizer state are put back afterwards."""
     from realvsr_amd import _lib as rlib
+    from realvsr_amd import functional as RF
     snap = _Snapshot(model)
     old = rlib.get_gemm_mode()
-    rlib.set_gemm_mode('f32')
+    rlib.set_gemm_mode(mode)
     try:
         ms, _, _ = timed_steps(model, steps, first_step)
     finally:
         rlib.set_gemm_mode(old)
         snap.restore()
+        RF.invalidate_weight_cache()
     return round(ms, 3)
+
+
+def f32_mode_step(model, first_step, steps=2):
+    return gemm_mode_step(model, first_step, 'f32', steps)
+
+
+GEMM_DESC = {'bf16x3': ' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)',
+             'bf16x2': ' (2-term bf16 split: weights rounded to bf16, activations hi + lo; v_mfma_f32_32x32x16_bf16, f32 accumulate)',
+             'bf16': ' (bf16 operands on v_mfma_f32_32x32x16_bf16, f32 accumulate)',
+             'f32': ' (v_mfma_f32_32x32x2_f32, exact f32)'}
+GEMM_PASSES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'f32': 1}
+
+
+def dtype_of(gemm_mode):
+    """Tensors, accumulation and all non-GEMM arithmetic are f32 in every mode; the product format is the GEMM mode."""
+    return 'f32' if gemm_mode == 'f32' else 'f32 (%s GEMM)' % gemm_mode
 
 
 def cpu_baseline(args, sd_in=None):
@@ -385,7 +404,20 @@ def parity_check(model, ora):
         den += float(g.double().pow(2).sum())
         if e > worst:
             worst, worst_name = e, k
+    # Two scale-free views of the output error.  (1) against the RESIDUAL branch: the output is bilinear(centre frame) + residual and a
+    # freshly initialised network's residual is small, so out_rel_err flatters; (2) what the error would do to a 30 dB model: PSNR-Y of
+    # both outputs against a synthetic target = oracle output + N(0, 10^(-30/20)) -- the north star's bound is 1e-3 dB
+    import torch.nn.functional as F
+    oc, oo = out.detach().float().cpu(), ora['out'].float()
+    base = F.interpolate(ora['x'][:, ora['x'].shape[1] // 2].float(), scale_factor=oo.shape[-1] // ora['x'].shape[-1], mode='bilinear', align_corners=False)
+    noise = torch.randn(oo[:, 0].shape, generator=torch.Generator().manual_seed(4321)) * 10 ** (-30 / 20)
+    target = oo[:, 0] + noise
+
+    def psnr(a):
+        return float(10 * torch.log10(1.0 / (a.double() - target.double()).pow(2).mean()))
     res = {'window': 'B=1, seeds 1234/1235, weights of the timed model', 'out_rel_err': float('%.3e' % l2(out, ora['out'])),
+           'residual_rel_err': float('%.3e' % float((oc - oo).double().norm() / ((oo - base).double().norm() + 1e-300))),
+           'psnr_y_delta_db_at_30db': float('%.3e' % abs(psnr(oc[:, 0]) - psnr(oo[:, 0]))),
            'out_max_abs_err': float('%.3e' % (out.detach().cpu() - ora['out']).abs().max().item()),
            'loss_rel_err': float('%.3e' % (abs(float(total.item()) - ora['loss']) / max(abs(ora['loss']), 1e-30))),
            'grad_l2_err_all': float('%.3e' % ((num / max(den, 1e-300)) ** 0.5)), 'worst_param': worst_name,
@@ -577,7 +609,7 @@ def main():
             print(json.dumps({'metric': 'HR frames/sec (fwd only, sliding window) on %d-frame %dx%d LR windows' % (N, H, W),
                               'value': round(world * 1e3 / ms, 3), 'unit': 'HR frames/s', 'n_gpus': world, 'steps': 10, 'warmup': 10,
                               'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                              'dtype': 'f32 (bf16x3 GEMM)' if gemm_mode == 'bf16x3' else 'f32', 'data': 'synthetic',
+                              'dtype': dtype_of(gemm_mode), 'data': 'synthetic',
                               'config': {'workload': res['workload'], 'parallelism': 'replicas x%d' % world, 'gemm': gemm_mode,
                                          'offset_abs_mean_px': res['offset_abs_mean_px']},
                               'roofline': {'kernel': 'fused DCN forward', 'bound': 'hbm', 'frac': res['dcn_fwd_frac'], 'peak': HBM_PEAK_GBS,
@@ -679,14 +711,13 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             # tensors, accumulation and all non-GEMM math are f32; the GEMM operands are config.gemm
-            'dtype': 'f32 (bf16x3 GEMM)' if gemm_mode == 'bf16x3' else 'f32',
+            'dtype': dtype_of(gemm_mode),
             'data': 'synthetic',
             'config': {'workload': 'EDVR%s nf%d, %d-frame %dx%d LR windows, batch %d per GPU, x4 output, VideoSRModel.'
                                    'optimize_parameters: fwd + %s on Y + GWLoss on CbCr + bwd + Adam step'
                                    % ('-M' if args.nf == 64 else '', args.nf, N, H, W, B, lf),
                        'per_gpu_batch': B, 'global_batch': world * B, 'parallelism': 'sequence-dp%d' % world,
-                       'gemm': gemm_mode + (' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)'
-                                            if gemm_mode == 'bf16x3' else ' (v_mfma_f32_32x32x2_f32, exact f32)'),
+                       'gemm': gemm_mode + GEMM_DESC[gemm_mode],
                        'lf_term': 'ssim (restated IQA_pytorch.SSIM, parity unpinned)' if args.lf_mode == 'ssim' else 'cb',
                        'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 4),
                        'offset_abs_max_px': None if l1[1] is None else round(l1[1], 3),
@@ -722,10 +753,24 @@ def main():
                                                 pxs=(3.0,) if args.offset_px is not None else (1.0, 3.0))
             if gemm_mode == 'bf16x3':
                 line['f32_mode_ms_per_step'] = f32_mode_step(model, nxt)
+                # the opt-in speed modes (realvsr_amd.set_gemm_mode): same step, 2 untimed + 3 timed; their parity rows follow below
+                line['speed_modes'] = {}
+                for m in ('bf16x2', 'bf16'):
+                    ms_m = gemm_mode_step(model, nxt, m, steps=3)
+                    line['speed_modes'][m] = {'gemm': m + GEMM_DESC[m], 'ms_per_step': ms_m,
+                                              'frames_per_s': round(B * world * 1e3 / ms_m, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ora = cpu_baseline(args, model.netG.state_dict())
             line['parity'] = parity_check(model, ora)
             line['parity']['gemm'] = gemm_mode
+            for m in line.get('speed_modes', {}):   # the same check in the speed modes
+                rlib.set_gemm_mode(m)
+                try:
+                    pm = parity_check(model, ora)
+                finally:
+                    rlib.set_gemm_mode(gemm_mode)
+                line['speed_modes'][m]['parity'] = {k: pm[k] for k in ('out_rel_err', 'residual_rel_err', 'psnr_y_delta_db_at_30db', 'out_max_abs_err',
+                                                                        'loss_rel_err', 'grad_l2_err_all', 'worst_param', 'worst_param_l2_err')}
             del ora
         if world == 1 and not args.no_extra and args.config == 2:
             del model, x, gt, timer

@@ -99,21 +99,31 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         mode = os.environ.get('RVSR_GEMM', 'bf16x3')
-        if mode not in ('bf16x3', 'f32'):
-            raise RuntimeError("RVSR_GEMM must be 'bf16x3' or 'f32', got %r" % mode)
-        handle.rvsr_set_gemm_mode(1 if mode == 'f32' else 0)
+        if mode not in GEMM_MODES:
+            raise RuntimeError("RVSR_GEMM must be one of %s, got %r" % (sorted(GEMM_MODES), mode))
+        handle.rvsr_set_gemm_mode(GEMM_MODES[mode])
         _lib = handle
     return _lib
 
 
+GEMM_MODES = {'bf16x3': 0, 'f32': 1, 'bf16x2': 2, 'bf16': 3}
+
+
 def set_gemm_mode(mode):
-    """'bf16x3' (default: 3-term bf16 split on the bf16 matrix cores, ~2^-17 relative error per
-    product) or 'f32' (exact-f32 MFMA, bit-for-bit an fmaf chain, ~5x slower GEMMs)."""
-    lib().rvsr_set_gemm_mode({'bf16x3': 0, 'f32': 1}[mode])
+    """How the matrix cores form a product (tensors, accumulation and all other arithmetic are f32 in every mode):
+    'bf16x3' (default) three-term bf16 split, ~2^-17 relative error per product -- f32-grade results;
+    'f32'    exact-f32 MFMA, bit-for-bit an fmaf chain, ~5x slower GEMMs;
+    'bf16x2' two terms: the weights (in a weight gradient: the output gradient) are rounded to bf16, the other operand stays a hi + lo
+             pair -- ~2^-9 per product, i.e. the network with bf16-rounded weights evaluated on f32 activations;
+    'bf16'   one term, both operands rounded to bf16 (the usual mixed-precision product).
+    The reduced-term modes are opt-in speed modes of conv_fwd5 / conv_wgrad2 / the DCN kernels (every other kernel keeps three terms);
+    tests/test_gpu_modes.py holds them to the 1e-3 dB PSNR bound of the north star."""
+    lib().rvsr_set_gemm_mode(GEMM_MODES[mode])
 
 
 def get_gemm_mode():
-    return 'f32' if lib().rvsr_get_gemm_mode() else 'bf16x3'
+    m = lib().rvsr_get_gemm_mode()
+    return [k for k, v in GEMM_MODES.items() if v == m][0]
 
 
 def check(rc, what):

@@ -473,7 +473,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
 // rows): a wave then owns 256 contiguous bytes of every output channel row, and the epilogue (conv2_epilogue_wide) writes them as
 // 4 channels x 256 B per instruction instead of 8 channels x 128 B -- the CU's store path takes a 256-byte run at the price of a
 // 128-byte one (tools/micro/store_micro.hip: 26.5 vs 13.5 B/clk), and the output burst of a tile was 15 % of the training step.
-template <int MT, bool ACT_IN, int VEC, bool WIDE = false>
+// NT: terms of the bf16 product (rvsr_set_gemm_mode): 3 = hi*hi + hi*lo + lo*hi (f32-grade, the default); 2 = the weights' lo part is
+// dropped (W rounded to bf16, activations / gradients full: two MFMAs per product, the lo half of the weight image is neither loaded nor
+// published); 1 = plain bf16 operands (one MFMA, no lo image of the input tile either).  Accumulation is f32 in every mode.
+template <int MT, bool ACT_IN, int VEC, bool WIDE = false, int NT = 3>
 __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p) {
     constexpr int KS = 3, T = 9, PAD = 1, NW = 8, TH = WIDE ? NW : 2 * NW, TW = WIDE ? 64 : 32, NTHR = NW * 64;
     constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
@@ -525,7 +528,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
     // buffer views (VEC staging): the packed weight image, and the current tile's batch element of each input / of act'
     __amdgpu_buffer_rsrc_t w_rs = buf_view_2g(p.wpack), xa_rs = buf_view_2g(va.p), xb_rs = buf_view_2g(va.p), act_rs = buf_view_2g(va.p);
     constexpr int NIT = VEC ? 1 : (NX + NTHR - 1) / NTHR;  // input items per thread
-    constexpr int NWV = (2 * WVEC + NTHR - 1) / NTHR;      // weight vectors per thread
+    constexpr int WPARTS = NT >= 3 ? 2 : 1;                // parts of the weight image this kernel reads: [hi | lo] or hi only
+    constexpr int NWV = (WPARTS * WVEC + NTHR - 1) / NTHR; // weight vectors per thread
     constexpr int NV = VEC ? 4 : 1;                        // pixels per item
     int it_oc[NIT], it_sp[NIT], it_dst[NIT];
     bool it_pos_ok[NIT];
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             for (int i = 0; i < NWV; ++i) {
                 if (wsel >= 0 && wsel != i) continue;
                 const int e = tid + i * NTHR;
-                const unsigned vo = e < 2 * WVEC ? (unsigned)tid * 16u : 0x80000000u;   // (only the last vector is ragged)
+                const unsigned vo = e < WPARTS * WVEC ? (unsigned)tid * 16u : 0x80000000u;   // (only the last vector is ragged)
                 const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)vo, (int)(wbase + (unsigned)i * NTHR * 16u), 0);
                 wv[i] = __builtin_bit_cast(bf16x8, w);
             }
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
         for (int i = 0; i < NWV; ++i) {
             if (wsel >= 0 && wsel != i) continue;
             const int e = tid + i * NTHR;
-            wv[i] = src[e < 2 * WVEC ? e : 0];
+            wv[i] = src[e < WPARTS * WVEC ? e : 0];
         }
         if (xsel >= 8) return;
         const int c0 = chunk * 16;
@@ -730,14 +734,14 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 bf16x8* const dh = ok ? xs_hi + dst : sink;
                 bf16x8* const dl = ok ? xs_lo + dst : sink;
                 *dh = h8;
-                *dl = l8;
+                if (NT >= 2) *dl = l8;
             }
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             if (wsel >= 0 && wsel != i) continue;
             const int e = tid + i * NTHR;
-            *(e < 2 * WVEC ? ws + e : sink) = wv[i];
+            *(e < WPARTS * WVEC ? ws + e : sink) = wv[i];
         }
     };
     // bias of tile k lives in slot k & 3: tiles k-1 .. k+1 can be alive at once when a tile is a single stage
@@ -803,13 +807,13 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 ah[slot][m] = ws_hi[(tap * NOCT + hi) * MP + m * 32 + lo];
-                al[slot][m] = ws_lo[(tap * NOCT + hi) * MP + m * 32 + lo];
+                if (NT >= 3) al[slot][m] = ws_lo[(tap * NOCT + hi) * MP + m * 32 + lo];
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int idx = WIDE ? (hi * IH + wave + dy) * IW + lo + 32 * n + dx : (hi * IH + wave * 2 + n + dy) * IW + lo + dx;
                 bh[slot][n] = xs_hi[idx];
-                bl[slot][n] = xs_lo[idx];
+                if (NT >= 2) bl[slot][n] = xs_lo[idx];
             }
         };
         fetch(0, 0);
@@ -824,14 +828,18 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bh[sl][n], acc[m][n]);
+            if (NT >= 2) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bl[sl][n], acc[m][n]);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(ah[sl][m], bl[sl][n], acc[m][n]);
+            }
+            if (NT >= 3) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[sl][m], bh[sl][n], acc[m][n]);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[sl][m], bh[sl][n], acc[m][n]);
+            }
             // ---- this wave's own staging work, a slice per tap, in the shadow of the MFMAs above (a wave's own
             // VALU/LDS instructions fill its MFMA issue gaps; another wave's barely do):
             //   taps 0-3: publish pixel / item `tap` of stage q+1 (registers loaded during stage q-1)
@@ -1193,6 +1201,17 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
                                   : vec ? conv_fwd5_kernel<MT, true, 1> : conv_fwd5_kernel<MT, true, 0>)
                                : (vec == 3 ? conv_fwd5_kernel<MT, false, 3> : vec == 2 ? conv_fwd5_kernel<MT, false, 2>
                                   : vec ? conv_fwd5_kernel<MT, false, 1> : conv_fwd5_kernel<MT, false, 0>);
+    // reduced-term products (gemm modes 2 / 3): the 64-row m-block kernels on the vector-staged views; everything else keeps three terms
+    const int nt = (MT == 2 && vec != 0) ? rvsr_gemm_terms() : 3;
+    if constexpr (MT == 2) {
+#define FWD5_NT(NTV)                                                                                                                   \
+        k = va.act != nullptr ? (vec == 3 ? conv_fwd5_kernel<MT, true, 3, false, NTV> : vec == 2 ? conv_fwd5_kernel<MT, true, 2, false, NTV> \
+                                                                                      : conv_fwd5_kernel<MT, true, 1, false, NTV>)      \
+                              : (vec == 3 ? conv_fwd5_kernel<MT, false, 3, false, NTV> : vec == 2 ? conv_fwd5_kernel<MT, false, 2, false, NTV> \
+                                                                                       : conv_fwd5_kernel<MT, false, 1, false, NTV>)
+        if (nt == 2) { FWD5_NT(2); } else if (nt == 1) { FWD5_NT(1); }
+#undef FWD5_NT
+    }
     // tile shape: 8 x 64 (256-byte output runs, 16-byte stores, plain vector-staged view) when it wastes no more pixels than 16 x 32
     int th = 16, tw = 32;
     size_t lds_k = lds;
@@ -1203,11 +1222,13 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
         if (p.act == 3 && !(wide_ok && vec == 1 && p.vec4 && px_w <= px_n)) return RVSR_ERR_UNSUPPORTED;   // (mask epilogue: 8 x 64 tile only)
         if (wide_ok && vec == 1 && p.vec4 && px_w <= px_n) {
             k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true> : conv_fwd5_kernel<MT, false, 1, true>;
+            if (nt == 2) k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true, 2> : conv_fwd5_kernel<MT, false, 1, true, 2>;
+            if (nt == 1) k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true, 1> : conv_fwd5_kernel<MT, false, 1, true, 1>;
             th = 8; tw = 64;
             constexpr int NXW = 2 * 10 * 66;
             lds_k = (size_t)16 * (2 * 2 * NXW + 2 * 2 * WVEC) + sizeof(float) * 4 * MT * 32 + 16;
             static const int one_wave = [] { const char* e = getenv("RVSR_CONV_FWD6"); return e ? atoi(e) : 0; }();   // developer A/B switch
-            if (one_wave && p.act != 3) {   // four waves per workgroup, one per SIMD (conv_fwd6_kernel)
+            if (one_wave && p.act != 3 && nt == 3) {   // four waves per workgroup, one per SIMD (conv_fwd6_kernel)
                 auto k6 = va.act != nullptr ? conv_fwd6_kernel<true> : conv_fwd6_kernel<false>;
                 if (set_lds(k6, lds_k)) FAIL(RVSR_ERR_LAUNCH, "conv_fwd6: cannot reserve %zu B of LDS", lds_k);
                 const long items6 = (long)((p.Wout + 63) / 64) * ((p.Hout + 7) / 8) * ((p.Co + 63) / 64) * p.B;
@@ -1336,26 +1357,37 @@ __device__ __forceinline__ bf16x8 take8(u32x4 a, u32x4 b) {
 // one (dy) row of taps for one accumulator group: DXMASK selects which dx (bit 0..2) this wave owns.
 // The split terms are issued as sweeps over the row's independent accumulators (no back-to-back
 // dependent MFMAs).
-template <int DXMASK>
+// NT: terms of the product (rvsr_common.h): 3 = hi*hi + hi*lo + lo*hi; 2 = without the lo part of the output gradient; 1 = hi*hi
+template <int DXMASK, int NT>
 __device__ __forceinline__ void wg2_row(const unsigned char* xs_hi, const unsigned char* xs_lo, int xoff, bf16x8 ah,
                                         bf16x8 al, f32x16* acc) {
     const u32x4 h0 = *reinterpret_cast<const u32x4*>(xs_hi + xoff), h1 = *reinterpret_cast<const u32x4*>(xs_hi + xoff + 16);
-    const u32x4 l0 = *reinterpret_cast<const u32x4*>(xs_lo + xoff), l1 = *reinterpret_cast<const u32x4*>(xs_lo + xoff + 16);
     constexpr int N = ((DXMASK >> 0) & 1) + ((DXMASK >> 1) & 1) + ((DXMASK >> 2) & 1);
     bf16x8 bh[3], bl[3];
     int t = 0;
-    if (DXMASK & 1) { bh[t] = take8<3>(h0, h1); bl[t] = take8<3>(l0, l1); ++t; }
-    if (DXMASK & 2) { bh[t] = take8<4>(h0, h1); bl[t] = take8<4>(l0, l1); ++t; }
-    if (DXMASK & 4) { bh[t] = take8<5>(h0, h1); bl[t] = take8<5>(l0, l1); ++t; }
+    if (DXMASK & 1) { bh[t] = take8<3>(h0, h1); ++t; }
+    if (DXMASK & 2) { bh[t] = take8<4>(h0, h1); ++t; }
+    if (DXMASK & 4) { bh[t] = take8<5>(h0, h1); ++t; }
+    if (NT >= 2) {
+        const u32x4 l0 = *reinterpret_cast<const u32x4*>(xs_lo + xoff), l1 = *reinterpret_cast<const u32x4*>(xs_lo + xoff + 16);
+        t = 0;
+        if (DXMASK & 1) { bl[t] = take8<3>(l0, l1); ++t; }
+        if (DXMASK & 2) { bl[t] = take8<4>(l0, l1); ++t; }
+        if (DXMASK & 4) { bl[t] = take8<5>(l0, l1); ++t; }
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(ah, bh[i], acc[i]);
+    if (NT >= 2) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(ah, bl[i], acc[i]);
+        for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(ah, bl[i], acc[i]);
+    }
+    if (NT >= 3) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(al, bh[i], acc[i]);
+        for (int i = 0; i < N; ++i) acc[i] = mfma_bf16(al, bh[i], acc[i]);
+    }
 }
 
-template <bool ACT, int GMODE>
+template <bool ACT, int GMODE, int NT = 3>
 __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvWgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* gs_hi = smem_raw;                  // [64 o][WG2_GP]
@@ -1539,7 +1571,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             bf16x8 h8, l8;
             split8(v, h8, l8);
             *reinterpret_cast<bf16x8*>(gs_hi + g_lds[i]) = h8;
-            *reinterpret_cast<bf16x8*>(gs_lo + g_lds[i]) = l8;
+            if (NT >= 3) *reinterpret_cast<bf16x8*>(gs_lo + g_lds[i]) = l8;
         }
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
@@ -1556,7 +1588,7 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
             slot = slot >= 6 ? slot - 6 : slot;
             const int dst = x_lds[i] + slot * 80;
             *reinterpret_cast<bf16x8*>(xs_hi + dst) = h8;
-            *reinterpret_cast<bf16x8*>(xs_lo + dst) = l8;
+            if (NT >= 2) *reinterpret_cast<bf16x8*>(xs_lo + dst) = l8;
         }
     };
 
@@ -1595,15 +1627,15 @@ __global__ __launch_bounds__(WG2_THREADS, 2) void conv_wgrad2_kernel(const ConvW
                 const int row = ks >> 1, cb = (ks & 1) * 16 + 8 * hi;  // this lane's 8 pixels: row, cols cb..cb+7
                 const int goff = (m * 32 + lo) * WG2_GP + row * 64 + cb * 2;
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(gs_hi + goff);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(gs_lo + goff);
+                const bf16x8 al = NT >= 3 ? *reinterpret_cast<const bf16x8*>(gs_lo + goff) : ah;
                 // X octet pair holding stored cols cb .. cb+15 (= image cols x0-4+cb ..); tap dx needs +3+dx
                 const int xbase = (chalf * 32 + lo) * WG2_XP + cb * 2;
                 if (!second) {  // taps (0,0) (0,1) (0,2) (1,0) (1,1)
-                    wg2_row<7>(xs_hi, xs_lo, xbase + roff[row + 0], ah, al, acc + 0);
-                    wg2_row<3>(xs_hi, xs_lo, xbase + roff[row + 1], ah, al, acc + 3);
+                    wg2_row<7, NT>(xs_hi, xs_lo, xbase + roff[row + 0], ah, al, acc + 0);
+                    wg2_row<3, NT>(xs_hi, xs_lo, xbase + roff[row + 1], ah, al, acc + 3);
                 } else {        // taps (1,2) (2,0) (2,1) (2,2)
-                    wg2_row<4>(xs_hi, xs_lo, xbase + roff[row + 1], ah, al, acc + 0);
-                    wg2_row<7>(xs_hi, xs_lo, xbase + roff[row + 2], ah, al, acc + 1);
+                    wg2_row<4, NT>(xs_hi, xs_lo, xbase + roff[row + 1], ah, al, acc + 0);
+                    wg2_row<7, NT>(xs_hi, xs_lo, xbase + roff[row + 2], ah, al, acc + 1);
                 }
             }
         }
@@ -1653,6 +1685,11 @@ int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_
     const bool act = p.g.act != nullptr;
     auto k = p.g.mode == 0 ? (act ? conv_wgrad2_kernel<true, 0> : conv_wgrad2_kernel<false, 0>)
                            : (act ? conv_wgrad2_kernel<true, 2> : conv_wgrad2_kernel<false, 2>);
+    const int nt = rvsr_gemm_terms();   // reduced-term products (gemm modes 2 / 3)
+    if (nt == 2) k = p.g.mode == 0 ? (act ? conv_wgrad2_kernel<true, 0, 2> : conv_wgrad2_kernel<false, 0, 2>)
+                                   : (act ? conv_wgrad2_kernel<true, 2, 2> : conv_wgrad2_kernel<false, 2, 2>);
+    if (nt == 1) k = p.g.mode == 0 ? (act ? conv_wgrad2_kernel<true, 0, 1> : conv_wgrad2_kernel<false, 0, 1>)
+                                   : (act ? conv_wgrad2_kernel<true, 2, 1> : conv_wgrad2_kernel<false, 2, 1>);
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "conv_wgrad2: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL(k, dim3(p.P, gy, gz), dim3(WG2_THREADS), lds, st, p);
     hipError_t e = hipGetLastError();

@@ -86,8 +86,7 @@ struct ConvWgradParams {
 // bf16x3 path (conv2_kernels.hip)
 size_t rvsr_conv_fwd2_workspace_bytes(int ksize, int Co, int Ctot);
 int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspace, size_t workspace_bytes, hipStream_t st);
-// 0: bf16x3 split GEMM (default), 1: exact-f32 MFMA everywhere
-extern int rvsr_g_gemm_mode;
+
 int rvsr_launch_conv_wgrad2(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
 int rvsr_launch_conv_wgrad1x1(const ConvWgradParams& p, int gy, int gz, hipStream_t st);
 int rvsr_launch_conv_wgrad_s2(const ConvWgradParams& p, int gy, int gz, hipStream_t st);

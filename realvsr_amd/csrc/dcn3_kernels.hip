@@ -97,12 +97,15 @@ __device__ __forceinline__ f32x2 blend4(f32x2 s, f32x2 t, f32x2 a00, f32x2 a01, 
 // (rvsr_launch_dcn_fwd3): every candidate returns at once unless the counters select it, so that px-scale offsets sample from LDS
 // instead of gathering from global memory lane by lane (3 px mean |offset|: 0.19 -> see profiles/r03_notes.md).  pad + R is a
 // multiple of 4 for all three: tile rows start on 16-byte boundaries and the large tiles are staged with 16-byte loads.
-template <int MT, int R>
+// TERMS: terms of the bf16 product (rvsr_common.h: gemm modes): 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part (that half of
+// the weight slice is not fetched); 1 = hi*hi (no lo part of the column values either)
+template <int MT, int R, int TERMS = 3>
 __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
     constexpr int TR = TH + 2 * R + 2, TC = 32 + 2 * R + 2, NPOS = TR * TC;
     constexpr int MP = MT * 32, WVEC = 9 * 2 * MP;  // 16-byte vectors per weight part
-    constexpr int NWV = (2 * WVEC + NT - 1) / NT;
+    constexpr int WPARTS = TERMS >= 3 ? 2 : 1;      // parts of the weight slice this kernel uses: [hi | lo] or hi only
+    constexpr int NWV = (WPARTS * WVEC + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);           // [2 octets][2 halves][NPOS], zero outside the image
     bf16x8* ws_hi = reinterpret_cast<bf16x8*>(xt + 4 * NPOS);   // [9 taps][2 octets][MP]
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
 #pragma unroll
             for (int i = 0; i < NWV; ++i) {
                 const int e = tid + i * NT;
-                if (e - lane + 63 < 2 * WVEC)   // (wave-uniform; 2 * WVEC is a multiple of 64)
+                if (e - lane + 63 < WPARTS * WVEC)   // (wave-uniform; WVEC is a multiple of 64)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e),
                                                      (__attribute__((address_space(3))) void*)(ws_hi + e), 16, 0, 0);
             }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 ah[mt] = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
-                al[mt] = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
+                if (TERMS >= 3) al[mt] = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
             }
 #ifdef RVSR_F3_PRIO   // (scratch variant, tools/build_variant_f3.sh: priority of the wave while it feeds the matrix core)
             __builtin_amdgcn_s_setprio(1);
@@ -288,9 +291,9 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bh, acc[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bl, acc[mt]);
+            for (int mt = 0; mt < MT; ++mt) if (TERMS >= 2) acc[mt] = mfma_bf16(ah[mt], bl, acc[mt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
+            for (int mt = 0; mt < MT; ++mt) if (TERMS >= 3) acc[mt] = mfma_bf16(al[mt], bh, acc[mt]);
 #ifdef RVSR_F3_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -355,6 +358,11 @@ static int launch_dcn_fwd3(const DcnFwdParams& p, const bf16x8* wpack, hipStream
     constexpr int TH = 8, TR = TH + 2 * R + 2, TC = 32 + 2 * R + 2;
     const size_t lds = (size_t)16 * (4 * TR * TC + 2 * 9 * 2 * MT * 32) + sizeof(float) * MT * 32;
     auto k = dcn_fwd3_kernel<MT, R>;
+    if constexpr (MT >= 2) {   // reduced-term products (gemm modes 2 / 3): the kernels of the nf64 / nf128 packs
+        const int nt = rvsr_gemm_terms();
+        if (nt == 2) k = dcn_fwd3_kernel<MT, R, 2>;
+        if (nt == 1) k = dcn_fwd3_kernel<MT, R, 1>;
+    }
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_fwd3: cannot reserve %zu B of LDS", lds);
     const DcnGeom& d = p.d;
     dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), (d.Co + MT * 32 - 1) / (MT * 32), d.B);

@@ -136,4 +136,4 @@ size_t rvsr_dcn_bwdin5_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1,
                            const unsigned* probe_in = nullptr);
-extern int rvsr_g_gemm_mode;
+

@@ -382,7 +382,7 @@ static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, 
     DcnFwdParams p;
     p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act & 0xff; p.slope = slope; p.prepacked = prepacked;
     p.sel = dcn_halo_always();
-    if (rvsr_g_gemm_mode == 0 && workspace != nullptr) {  // bf16x3 second-generation kernel
+    if (rvsr_g_gemm_mode != 1 && workspace != nullptr) {  // bf16x3 second-generation kernel
         // `probe`: three zeroed device counters; filled with the offset statistic that selects the tile halo on the device (and that
         // the backward of the same layer reuses)
         size_t nprobe = 0;
@@ -451,7 +451,7 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
-        if (rvsr_g_gemm_mode == 0) {
+        if (rvsr_g_gemm_mode != 1) {
             static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 6; }();  // developer A/B switch
             static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
             if (gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);

@@ -261,3 +261,11 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t rs, unsigned l
 __device__ __forceinline__ void buf_atomic_add(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes, float v) {
     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rs, (int)lane_bytes, (int)uniform_bytes, 0);
 }
+
+// GEMM mode of the library (rvsr_set_gemm_mode, conv_kernels.hip): 0 = bf16x3 split products (hi*hi + hi*lo + lo*hi: f32-grade, the
+// default); 1 = exact-f32 MFMA everywhere; 2 = bf16x2 (two terms: the weights -- or, in a weight gradient, the output gradient -- are
+// rounded to bf16, the other operand stays a hi + lo pair); 3 = plain bf16 operands (one term).  Accumulation is f32 in every mode.  The
+// reduced-term modes exist in the kernels that dominate a training step (conv_fwd5, conv_wgrad2, the DCN kernels); every other
+// split-GEMM kernel keeps three terms in all of them.
+extern int rvsr_g_gemm_mode;
+static inline int rvsr_gemm_terms() { return rvsr_g_gemm_mode == 2 ? 2 : (rvsr_g_gemm_mode == 3 ? 1 : 3); }

@@ -187,7 +187,7 @@ class PackedWeights:
 
     def get(self, weight, kind, C_in, Co, k, w_mode, nbytes):
         """Packed image tensor for (weight, kind, geometry), or None when the weight is not cacheable."""
-        if not self.enabled or _lib.get_gemm_mode() != 'bf16x3':
+        if not self.enabled or _lib.get_gemm_mode() == 'f32':
             return None
         if getattr(weight, '_rvsr_grad_home', None) is None and getattr(weight, '_rvsr_parent', None) is None:
             return None

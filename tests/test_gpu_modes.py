@@ -1,0 +1,148 @@
+"""The reduced-term GEMM modes ('bf16x2', 'bf16': realvsr_amd.set_gemm_mode) -- opt-in speed modes of conv_fwd5 / conv_wgrad2 /
+dcn_fwd3; the default stays the f32-grade three-term split.
+
+What they are held to:
+  * DEFINITION, bit for bit: a product of operands that are already bf16 values has no lo part, so the three-term kernel run on
+    pre-rounded operands must produce the very bits of the reduced-term kernel run on the original ones ('bf16x2': weights pre-rounded;
+    'bf16': weights and input pre-rounded) -- this pins WHICH term each mode drops;
+  * operator error against f64: ~2^-9 per product (bf16 rounding of one / both operands), far from the 1e-5 of the default;
+  * the north star's bound on the network: PSNR within 1e-3 dB of the reference path (here: PSNR-Y of the build's and the oracle's
+    output against a synthetic 30 dB target, and the error of the residual branch itself, at BASELINE config 2's full window)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from gpu_util import dev, l2_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=['bf16x2', 'bf16'])
+def speed_mode(request):
+    from realvsr_amd import _lib
+    old = _lib.get_gemm_mode()
+    _lib.set_gemm_mode(request.param)
+    yield request.param
+    _lib.set_gemm_mode(old)
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _conv_case(seed=5, B=2, C=64, Co=64, H=40, W=64):
+    torch.manual_seed(seed)
+    conv = nn.Conv2d(C, Co, 3, 1, 1).to(dev())
+    x = torch.randn(B, C, H, W, device=dev())
+    return conv, x
+
+
+def test_conv_forward_is_the_three_term_kernel_on_rounded_operands(speed_mode):
+    from realvsr_amd import _lib
+    from realvsr_amd import functional as RF
+    conv, x = _conv_case()
+    with torch.no_grad():
+        y = RF.conv2d(x, conv, RF.ACT_LRELU)
+        _lib.set_gemm_mode('bf16x3')
+        conv_r = nn.Conv2d(64, 64, 3, 1, 1).to(dev())
+        conv_r.weight.copy_(_bf16(conv.weight))
+        conv_r.bias.copy_(conv.bias)
+        y_r = RF.conv2d(_bf16(x) if speed_mode == 'bf16' else x, conv_r, RF.ACT_LRELU)
+        _lib.set_gemm_mode(speed_mode)
+    assert torch.equal(y, y_r), (speed_mode, (y - y_r).abs().max().item())
+
+
+def test_conv_block_against_f64(speed_mode):
+    from realvsr_amd import functional as RF
+    conv, x = _conv_case(seed=6)
+    x.requires_grad_(True)
+    # (no activation: an output that moves by 2e-3 flips the LeakyReLU mask of ~1e-3 of the elements, and the gradient of the computed
+    # forward then differs from the reference's by 3e-2 in L2 -- a property of the kink, not of the products under test)
+    y = RF.conv2d(x, conv, RF.ACT_NONE)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, bd, padding=1)
+    yd.backward(g.double())
+    tol = {'bf16x2': 4e-3, 'bf16': 6e-3}[speed_mode]
+    for name, a, b in (('out', y, yd), ('grad_x', x.grad, xd.grad), ('grad_w', conv.weight.grad, wd.grad), ('grad_b', conv.bias.grad, bd.grad)):
+        e = l2_err(a, b.float())
+        print('%s %-8s l2_err %.3e (tol %.1e)' % (speed_mode, name, e, tol))
+        assert e <= tol, (name, e)
+    # and it IS a reduced-term product: an f32-grade result would sit at ~1e-6
+    assert l2_err(y, yd.float()) > 2e-4
+
+
+def test_dcn_pack_forward(speed_mode):
+    """dcn_fwd3 in the speed modes: 'bf16x2' = the three-term kernel on bf16-rounded weights, bit for bit; 'bf16' additionally rounds the
+    sampled column values (not an input one could pre-round): bounded against the three-term result."""
+    from realvsr_amd import _lib
+    from realvsr_amd import functional as RF
+    torch.manual_seed(11)
+    B, C, H, W, dg = 2, 64, 40, 64, 8
+    x = torch.randn(B, C, H, W, device=dev())
+    om = torch.randn(B, 27 * dg, H, W, device=dev())
+    om[:, :18 * dg] *= 1.25
+    w = (torch.randn(C, C, 3, 3, device=dev()) / 24).requires_grad_(True)   # (needs_input_grad -> the training path, no probe pass)
+    b = torch.randn(C, device=dev())
+    y = RF.dcn_pack(x, om, w, b, 1, 1, 1, dg, RF.ACT_LRELU, 0.1).detach()
+    _lib.set_gemm_mode('bf16x3')
+    wr = _bf16(w.detach()).requires_grad_(True)
+    y3r = RF.dcn_pack(x, om, wr, b, 1, 1, 1, dg, RF.ACT_LRELU, 0.1).detach()
+    y3 = RF.dcn_pack(x, om, w, b, 1, 1, 1, dg, RF.ACT_LRELU, 0.1).detach()
+    _lib.set_gemm_mode(speed_mode)
+    if speed_mode == 'bf16x2':
+        assert torch.equal(y, y3r), (y - y3r).abs().max().item()
+    e = l2_err(y, y3)
+    print('%s dcn_pack forward against the three-term kernel: l2_err %.3e' % (speed_mode, e))
+    assert 2e-4 < e <= 6e-3, e
+
+
+@pytest.mark.parametrize('mode', ['bf16x2', 'bf16'])
+def test_config2_window_holds_the_north_star_psnr_bound(mode):
+    """BASELINE config 2's window (EDVR-M nf64, 5 x 180 x 320, offsets rescaled to 1 px) in a speed mode against the CPU oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import edvr_oracle as O
+    from realvsr_amd import _lib
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    import bench
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.manual_seed(0)
+    N, H, W = 5, 180, 320
+    net = EDVR(nf=64, nc=3, nframes=N, groups=8, front_RBs=5, back_RBs=10, w_TSA=True)
+    gen = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if 'conv_offset_mask.weight' in name:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.01)
+    x = torch.rand(1, N, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    net = net.to(dev())
+    bench.offset_stats(net, x.to(dev()), 1.0)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        out_o = O.edvr_forward(sd, x, nframes=N, groups=8, front_RBs=5, back_RBs=10, w_TSA=True)
+    old = _lib.get_gemm_mode()
+    _lib.set_gemm_mode(mode)
+    try:
+        with torch.no_grad():
+            out = net(x.to(dev())).cpu()
+    finally:
+        _lib.set_gemm_mode(old)
+    base = F.interpolate(x[:, N // 2], scale_factor=4, mode='bilinear', align_corners=False)
+    res_err = float((out - out_o).double().norm() / (out_o - base).double().norm())
+    target = out_o[:, 0] + torch.randn(out_o[:, 0].shape, generator=torch.Generator().manual_seed(4321)) * 10 ** (-30 / 20)
+
+    def psnr(a):
+        return float(10 * torch.log10(1.0 / (a.double() - target.double()).pow(2).mean()))
+    d_psnr = abs(psnr(out[:, 0]) - psnr(out_o[:, 0]))
+    print('%s: residual-branch error %.3e, max |out - oracle| %.3e, |dPSNR-Y| against a 30 dB target %.2e dB'
+          % (mode, res_err, (out - out_o).abs().max().item(), d_psnr))
+    assert d_psnr <= 1e-3
+    assert res_err <= 1e-2
+    # a trained network's residual branch is O(0.05) of the [0, 1] range: even then this error moves a 30 dB PSNR by
+    # 4.34 * (res_err * 0.05 / 10^-1.5)^2 dB
+    assert 4.34 * (res_err * 0.05 / 10 ** -1.5) ** 2 <= 1e-3

@@ -38,5 +38,13 @@ e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / a.iters
 flop = 2.0 * a.C * 9 * a.Co * a.B * a.H * a.W * (3 if a.bwd else 1)
+if os.environ.get('RVSR_MICRO_CHECK'):
+    import torch.nn.functional as F
+    with torch.no_grad():
+        ref = F.conv2d(x[:2].double(), conv.weight.double(), conv.bias.double(), padding=1)
+        if not a.no_act:
+            ref = F.leaky_relu(ref, 0.1)
+        err = (y[:2].double() - ref).pow(2).sum().sqrt() / ref.pow(2).sum().sqrt()
+    print('  l2 error of the output against an f64 conv: %.2e' % err.item())
 print('conv %s: %.3f ms/iter, %.1f TFLOP/s (f32-equivalent), %.3f ns/px' % ('fwd+bwd' if a.bwd else 'fwd', ms, flop / ms / 1e9,
                                                                               ms * 1e6 / (a.B * a.H * a.W)))
