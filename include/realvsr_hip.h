@@ -43,7 +43,13 @@ const char* rvsr_last_error(void);
 
 /* GEMM arithmetic of the conv blocks: 0 (default) = 3-term bf16 split on the bf16 matrix cores
  * (a = a_hi + a_lo; a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in f32; ~2^-17 relative error
- * per product), 1 = exact f32 MFMA (an fmaf chain; ~5x slower GEMMs).  Process-wide switch. */
+ * per product), 1 = exact f32 MFMA (an fmaf chain; ~5x slower GEMMs).  Opt-in speed modes:
+ * 2 = two terms (the weights -- in a weight gradient: the output gradient -- rounded to bf16, the
+ * other operand hi + lo: exactly the result of mode 0 on bf16-rounded weights), 3 = one term (both
+ * operands rounded to bf16); accumulation stays f32, ~2^-9 per product.  Modes 2 / 3 act in the
+ * kernels that dominate a training step (3x3 stride-1 forward / data gradient / weight gradient
+ * with 64-row m-blocks, the fused DCN forward); every other kernel computes three terms in them.
+ * Other values select 0.  Process-wide switch. */
 void rvsr_set_gemm_mode(int mode);
 int rvsr_get_gemm_mode(void);
 

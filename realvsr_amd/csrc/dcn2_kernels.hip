@@ -1040,8 +1040,10 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
         // (dcn_bwdw4 addresses 64 gOut planes, 27 offset / mask planes and 8 x planes with 32-bit byte offsets inside 2 GB buffer views)
         const bool spans_ok = (size_t)256 * d.Ho * d.Wo < ((size_t)1 << 31) && (size_t)32 * d.H * d.W < ((size_t)1 << 31);
         if (gen >= 4 && d.stride == 1 && d.dil == 1 && g.mode == 0 && (d.Wo & 3) == 0 && p.gvec && spans_ok) {
-            if (set_lds(dcn_bwdw4_kernel, lds3)) return -2;
-            hipLaunchKernelGGL(dcn_bwdw4_kernel, dim3(P, gy, gz), dim3(512), lds3, st, p);
+            const int nt = rvsr_gemm_terms();   // reduced-term products (gemm modes 2 / 3)
+            auto k4 = nt == 2 ? dcn_bwdw4_kernel<2> : (nt == 1 ? dcn_bwdw4_kernel<1> : dcn_bwdw4_kernel<3>);
+            if (set_lds(k4, lds3)) return -2;
+            hipLaunchKernelGGL(k4, dim3(P, gy, gz), dim3(512), lds3, st, p);
             return 8 * P;
         }
         if (set_lds(dcn_bwdw3_kernel, lds3)) return -2;

@@ -164,7 +164,9 @@ __device__ __forceinline__ int fx_units(float w, float ts) {
     return (int)(__builtin_bit_cast(unsigned, __builtin_fmaf(w, ts, 12582912.f)) - 0x4B400000u);
 }
 
-template <int NK, int R>
+// TERMS: terms of the bf16 product W^T * gOut (rvsr_common.h: gemm modes): 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part;
+// 1 = hi*hi
+template <int NK, int R, int TERMS = 3>
 __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Params p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
     constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
@@ -307,8 +309,8 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
                 const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo], al = wb_lo[(2 * ks + hi) * 32 + lo];
                 if (RVSR_ABL5 & 16) { acc[0] += (float)ah[0] * (float)gh[ks][0] + (float)al[1] * (float)gl[ks][1]; continue; }
                 acc = mfma_bf16(ah, gh[ks], acc);
-                acc = mfma_bf16(ah, gl[ks], acc);
-                acc = mfma_bf16(al, gh[ks], acc);
+                if (TERMS >= 2) acc = mfma_bf16(ah, gl[ks], acc);
+                if (TERMS >= 3) acc = mfma_bf16(al, gh[ks], acc);
             }
             if (chunk == 1) TS5(90 + mt);
 #pragma unroll
@@ -469,6 +471,11 @@ static int launch_bwdin5(const DcnBwdIn5Params& p, const bf16x8* wpack, hipStrea
     constexpr int TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
     const size_t lds = (size_t)NPOS * (2 * 16 + 8 * 4) + (size_t)3 * 2 * (2 * NK) * 32 * 16 + 8 * sizeof(float);
     auto k = dcn_bwdin5_kernel<NK, R>;
+    if constexpr (NK >= 4) {   // reduced-term products (gemm modes 2 / 3): the kernels of the nf64 / nf128 packs
+        const int nt = rvsr_gemm_terms();
+        if (nt == 2) k = dcn_bwdin5_kernel<NK, R, 2>;
+        if (nt == 1) k = dcn_bwdin5_kernel<NK, R, 1>;
+    }
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin5: cannot reserve %zu B of LDS", lds);
     const DcnGeom& d = p.d;
     dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), 1, d.B);

@@ -100,6 +100,35 @@ def test_dcn_pack_forward(speed_mode):
     assert 2e-4 < e <= 6e-3, e
 
 
+def test_dcn_pack_backward(speed_mode):
+    """dcn_bwdin5 / dcn_bwdw4 in the speed modes against the three-term kernels on the same forward state (one seeded pack, 1.25 px
+    offsets): gradients of x, offsets + mask, weight and bias."""
+    from realvsr_amd import _lib
+    from realvsr_amd import functional as RF
+    torch.manual_seed(12)
+    B, C, H, W, dg = 2, 64, 40, 64, 8
+    x0 = torch.randn(B, C, H, W, device=dev())
+    om0 = torch.randn(B, 27 * dg, H, W, device=dev())
+    om0[:, :18 * dg] *= 1.25
+    w0 = torch.randn(C, C, 3, 3, device=dev()) / 24
+    b0 = torch.randn(C, device=dev())
+    g = torch.randn(B, C, H, W, device=dev())
+
+    def grads():
+        x, om, w, b = (t.clone().requires_grad_(True) for t in (x0, om0, w0, b0))
+        RF.dcn_pack(x, om, w, b, 1, 1, 1, dg, RF.ACT_NONE, 0.1).backward(g)
+        return x.grad, om.grad, w.grad, b.grad
+    got = grads()
+    _lib.set_gemm_mode('bf16x3')
+    ref = grads()
+    _lib.set_gemm_mode(speed_mode)
+    for name, a, r in zip(('grad_x', 'grad_offset_mask', 'grad_w', 'grad_b'), got, ref):
+        e = l2_err(a, r)
+        print('%s %-16s l2_err %.3e' % (speed_mode, name, e))
+        assert e <= 6e-3, (name, e)
+    assert l2_err(got[0], ref[0]) > 1e-4   # (it is a reduced-term product)
+
+
 @pytest.mark.parametrize('mode', ['bf16x2', 'bf16'])
 def test_config2_window_holds_the_north_star_psnr_bound(mode):
     """BASELINE config 2's window (EDVR-M nf64, 5 x 180 x 320, offsets rescaled to 1 px) in a speed mode against the CPU oracle."""
