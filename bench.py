@@ -301,16 +301,16 @@ def gemm_mode_step(model, first_step, mode, steps=2):
     old = rlib.get_gemm_mode()
     rlib.set_gemm_mode(mode)
     try:
-        ms, _, _ = timed_steps(model, steps, first_step)
+        ms, frac, bwd = timed_steps(model, steps, first_step)
     finally:
         rlib.set_gemm_mode(old)
         snap.restore()
         RF.invalidate_weight_cache()
-    return round(ms, 3)
+    return {'ms_per_step': round(ms, 3), 'dcn_fwd_frac': None if frac is None else round(frac, 4), 'dcn_bwd_ms_per_step': round(bwd, 3)}
 
 
 def f32_mode_step(model, first_step, steps=2):
-    return gemm_mode_step(model, first_step, 'f32', steps)
+    return gemm_mode_step(model, first_step, 'f32', steps)['ms_per_step']
 
 
 GEMM_DESC = {'bf16x3': ' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)',
@@ -462,6 +462,9 @@ def extra_train_line(base, nf, nframes, batch, steps=3):
            'dcn_fwd_frac': None if frac is None else round(frac, 4), 'dcn_bwd_ms_per_step': round(bwd, 2),
            'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3), 'conv_frac_of_bf16_peak': conv['frac'],
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    if rlib.get_gemm_mode() == 'bf16x3':   # the opt-in speed mode on the same workload (2 untimed + 2 timed steps)
+        r1 = gemm_mode_step(model, steps + 4, 'bf16', steps=2)
+        out['speed_mode_bf16'] = dict(r1, value=round(batch / (r1['ms_per_step'] * 1e-3), 3))
     del model, x, gt
     return out
 
@@ -510,6 +513,16 @@ def infer_line(a, T=10, offset_px=None):
            'note': 'the eager pass is GPU-bound at this frame size (no launch gaps), so the hipGraph replay of the window stage has '
                    'nothing to recover and pays for gathering the window into static buffers',
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    from realvsr_amd import _lib as rlib
+    if rlib.get_gemm_mode() == 'bf16x3':   # the opt-in speed mode on the same clip (eager)
+        rlib.set_gemm_mode('bf16')
+        try:
+            out1, ms1 = timed(run)
+        finally:
+            rlib.set_gemm_mode('bf16x3')
+        res['speed_mode_bf16'] = {'ms_per_frame': round(ms1, 2), 'value': round(1e3 / ms1, 3),
+                                  'max_abs_diff_of_the_output': float('%.3e' % (out1 - out).abs().max().item())}
+        del out1
     del net, clip, out, out_g, run, run_g
     return res
 
@@ -756,9 +769,8 @@ def main():
                 # the opt-in speed modes (realvsr_amd.set_gemm_mode): same step, 2 untimed + 3 timed; their parity rows follow below
                 line['speed_modes'] = {}
                 for m in ('bf16x2', 'bf16'):
-                    ms_m = gemm_mode_step(model, nxt, m, steps=3)
-                    line['speed_modes'][m] = {'gemm': m + GEMM_DESC[m], 'ms_per_step': ms_m,
-                                              'frames_per_s': round(B * world * 1e3 / ms_m, 2)}
+                    r_m = gemm_mode_step(model, nxt, m, steps=3)
+                    line['speed_modes'][m] = dict({'gemm': m + GEMM_DESC[m], 'frames_per_s': round(B * world * 1e3 / r_m['ms_per_step'], 2)}, **r_m)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'], ora = cpu_baseline(args, model.netG.state_dict())
             line['parity'] = parity_check(model, ora)
