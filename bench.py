@@ -242,7 +242,7 @@ class _Snapshot:
 def timed_steps(model, n, first_step):
     """3 untimed + n timed optimizer steps with the DCN timers installed: (ms/step, DCN fwd frac of the HBM peak, DCN bwd ms/step).
     (Three untimed steps: the first one after a change of offsets / GEMM mode re-sizes workspaces and allocator pools, and the DCN forward
-    picks its tile halo from the offset counters of three backwards ago, functional.DcnOffsetStats.LAG.)"""
+    picks its tile halo from the offset counters of three optimizer steps ago, functional.DcnOffsetStats.LAG.)"""
     for _ in range(3):
         model.optimize_parameters(first_step, log=False)
     timer = DcnTimer()

@@ -613,40 +613,58 @@ def grad_mask_fusable(H, W):
 class DcnOffsetStats:
     """Per DCN layer: the sampled offset counters of its last backwards (components beyond 2.5 .. 11.5 px), brought to the host with a
     non-blocking copy + event, so that a later forward of the layer can pick its LDS tile halo (3 / 7 / 11 px) on the host and launch
-    exactly one kernel.  The forward uses the counters of the backward LAG = 3 calls back and waits for that copy: the choice is a
-    function of the data, never of host timing (a query-and-keep-the-old-decision would make the kernel choice, and with it the last
-    bits of the forward, depend on how far the host happens to run ahead), and a host that is up to three steps ahead of the GPU --
-    which is what absorbs an 80 ms pause of Python's garbage collector, tools/cpu_launch_time.py -- never blocks on it.  Offsets of a
-    layer change slowly from step to step, and the choice affects speed and the last bits of rounding only (samples beyond the tile
-    gather from global memory with the same rules).  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the
-    components exceed 3.5 px, 7 px while < 1 % exceed 7.5 px, else 11 px (7 px above 64 output channels)."""
+    exactly one kernel.  The forward uses the counters recorded LAG = 3 OPTIMIZER STEPS back (`advance()`, called by FlatAdam.step; the
+    layer's last backward of that step) and waits for that copy: the choice is a function of the data, never of host timing (a
+    query-and-keep-the-old-decision would make the kernel choice, and with it the last bits of the forward, depend on how far the host
+    happens to run ahead), and a host that is up to three steps ahead of the GPU -- which is what absorbs an 80 ms pause of Python's
+    garbage collector, tools/cpu_launch_time.py -- never blocks on it, however many backwards per step a layer has (the per-frame PCD path
+    has N).  Without an optimizer that calls advance() the lag is counted in backwards of the layer instead.  Offsets of a layer change
+    slowly from step to step, and the choice affects speed and the last bits of rounding only (samples beyond the tile gather from global
+    memory with the same rules) -- which also means that data-parallel ranks, whose offsets differ, may run different tile sizes: their
+    forwards are equal to rounding, not bitwise.  Rule = the device-side rule of rvsr_launch_dcn_fwd3: 3 px while < 8 % of the components
+    exceed 3.5 px, 7 px while < 1 % exceed 7.5 px, else 11 px (7 px above 64 output channels)."""
     LAG = 3
 
     def __init__(self):
-        self.layers = {}     # id(weight) -> [weakref, ring of (pinned host counters, event, n_samples), records so far, decisions by record]
+        self.layers = {}     # id(weight) -> [weakref, ring of [pinned host counters, event, n_samples, tick], records so far, {tick: halo}]
+        self.step = None     # optimizer steps seen (None: nobody advances -- ticks are the layer's own record count)
+
+    def advance(self):
+        self.step = 1 if self.step is None else self.step + 1
+
+    def _tick(self, e):
+        return self.step if self.step is not None else e[2]
 
     def record(self, weight, probe_dev, nsamples):
         import weakref
         e = self.layers.get(id(weight))
         if e is None or e[0]() is not weight:
-            ring = [[torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0] for _ in range(self.LAG)]
+            ring = [[torch.zeros(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), 0, -1] for _ in range(self.LAG + 1)]
             e = [weakref.ref(weight), ring, 0, {}]
             self.layers[id(weight)] = e
             for k in [k for k, v in self.layers.items() if v[0]() is None]:
                 del self.layers[k]
-        slot = e[1][e[2] % self.LAG]
+        tick = self._tick(e)
+        slot = e[1][tick % (self.LAG + 1)]
         slot[0].copy_(probe_dev, non_blocking=True)
         slot[1].record()
         slot[2] = int(nsamples)
+        slot[3] = tick
+        e[3].pop(tick, None)
         e[2] += 1
 
     def forward_halo(self, weight, Co):
         e = self.layers.get(id(weight))
         if e is None or e[0]() is not weight or e[2] == 0:
             return 0
-        rec = max(e[2] - self.LAG, 0)            # the record this forward decides from (the oldest one in the ring; the first while it fills)
-        if rec not in e[3]:
-            c, ev, n = e[1][rec % self.LAG]
+        want = self._tick(e) - self.LAG
+        # the record of `want`; while the ring fills (or after steps without a backward of this layer): the oldest one it holds
+        live = [s for s in e[1] if s[3] >= 0]
+        older = [s for s in live if s[3] <= want]
+        slot = max(older, key=lambda s: s[3]) if older else min(live, key=lambda s: s[3])
+        tick = slot[3]
+        if tick not in e[3]:
+            c, ev, n = slot[0], slot[1], slot[2]
             ev.synchronize()
             if n == 0:
                 halo = 0
@@ -656,8 +674,8 @@ class DcnOffsetStats:
                 halo = 7
             else:
                 halo = 11
-            e[3] = {rec: halo}
-        return e[3][rec]
+            e[3] = {tick: halo}
+        return e[3][tick]
 
 
 dcn_offset_stats = DcnOffsetStats()

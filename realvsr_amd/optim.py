@@ -190,6 +190,7 @@ class FlatAdam(torch.optim.Optimizer):
             self.exp_avg_sq[s:e].copy_(m2)
         # the kernels above changed every parameter through raw pointers: re-pack all cached bf16 hi/lo weight images, one launch
         RF.packed_weights.repack()
+        RF.dcn_offset_stats.advance()   # (the DCN forwards' halo choice lags by optimizer steps, functional.DcnOffsetStats)
         return loss
 
     def load_state_dict(self, state_dict):

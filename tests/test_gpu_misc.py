@@ -196,3 +196,41 @@ def test_two_host_threads_two_streams():
             t.join()
         for i in range(2):
             assert torch.equal(got[i], ref[i]), i
+
+
+def test_dcn_offset_stats_lag_is_counted_in_optimizer_steps():
+    """functional.DcnOffsetStats: a forward decides from the layer's counters of LAG optimizer steps back, whatever the number of
+    backwards the layer has per step (the per-frame PCD path has N); without anybody calling advance() the lag counts the layer's own
+    backwards."""
+    import torch
+    from realvsr_amd.functional import DcnOffsetStats
+    d = torch.device('cuda:0')
+    n = 1000
+
+    def counters(halo):   # counters that make forward_halo answer `halo`
+        c = torch.zeros(8, dtype=torch.int32, device=d)
+        if halo >= 7:
+            c[1] = n          # everything beyond 3.5 px
+        if halo >= 11:
+            c[3] = n          # ... and beyond 7.5 px
+        return c
+    w = torch.nn.Parameter(torch.zeros(4, device=d))
+    st = DcnOffsetStats()
+    assert st.forward_halo(w, 64) == 0                 # no statistic yet
+    halos = [3, 7, 11, 3, 7, 11, 3, 7]
+    seen = []
+    for step, h in enumerate(halos):
+        st.advance()
+        seen.append(st.forward_halo(w, 64))
+        for _ in range(5):                             # five backwards of the layer in this step
+            st.record(w, counters(h), n)
+    # step s (1-based tick) sees the record of tick s - LAG; while the ring fills: the oldest record it holds
+    expect = [0] + [halos[max(s - DcnOffsetStats.LAG, 0)] for s in range(1, len(halos))]
+    assert seen == expect, (seen, expect)
+    # fallback: nobody advances -> the lag counts records
+    st2 = DcnOffsetStats()
+    seen2 = []
+    for h in halos:
+        seen2.append(st2.forward_halo(w, 64))
+        st2.record(w, counters(h), n)
+    assert seen2 == [0] + [halos[max(i - DcnOffsetStats.LAG, 0)] for i in range(1, len(halos))], seen2
