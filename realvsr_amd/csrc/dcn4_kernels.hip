@@ -34,6 +34,15 @@ extern "C" int rvsr_debug_read_dcn4(unsigned long long* out) { return (int)hipMe
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Timing ablations of scratch builds (tools/build_variant.sh dcn4_kernels <name> -DRVSR_ABL4=<bits>; results wrong by construction):
+// 1 no MFMAs (nor weight-fragment reads), 2 weight fragments from registers, 4 no corner reads, 8 no geometry arithmetic, 16 no blend / split,
+// 32 no offset / mask requests, 64 no barrier events (barriers, weight DMA, x staging)
+#ifdef RVSR_ABL4
+constexpr int ABL4 = RVSR_ABL4;
+#else
+constexpr int ABL4 = 0;
+#endif
+
 __device__ __forceinline__ f32x2v lo2v(const float4& a) { return f32x2v{a.x, a.y}; }
 __device__ __forceinline__ f32x2v hi2v(const float4& a) { return f32x2v{a.z, a.w}; }
 // s.x * a00 + t.x * a01 + s.y * a10 + t.y * a11 on a pair of channels (VOP3P op_sel / op_sel_hi pick the broadcast half)
@@ -208,16 +217,21 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
         if (wq < (both ? 2 : 1)) {   // (uniform)
             const unsigned voff = wv + (unsigned)(jl * WSLOT * 16);
             const unsigned m0v = ws_base + (unsigned)(jl * WSLOT * 16) + wconst;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(c.wsrc), "s"(m0v) : "memory", "m0");
+            unsigned keep;   // (M0 is a reserved register: saved and restored, not clobbered)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(c.wsrc), "s"(m0v) : "memory");
         }
     };
 
     // ---- offset / mask requests of k-step jj of c's period: three dword loads per lane
     struct Req { float dy, dx, m; };
     auto request = [&](Req& q, Fwd4Ctx& c, int jj) {
+        if (ABL4 & 32) { q.dy = __builtin_bit_cast(float, c.voff) * 1e-30f; q.dx = q.dy; q.m = 0.5f; }
+        else {
         q.dy = buf_load(c.rs, c.voff, 0u);
         q.dx = buf_load(c.rs, c.voff, hw4);
         q.m = buf_load(c.rs, c.vmsk, d.mdelta);
+        }
         // advance to the lane's next unit (u + 2): four offset planes / two mask planes further, except where the step crosses from
         // the period's first chunk into its second and both are the same deformable group (CPG8S == 1: taps 7, 8 -> 0, 1: -14 / -7)
         const int ul0 = 2 * jj, ul1 = 2 * jj + 1;
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
     };
     // ---- sampling geometry of that k-step from its offsets; xb0 / xb1 = (uniform) LDS byte addresses of the period's two chunk slots
     auto geometry = [&](Fwd4Geo& G, unsigned& flags, const Req& q, const Fwd4Ctx& c, int jj, unsigned xb0, unsigned xb1) {
+        if (ABL4 & 8) { G.addr = xb0 + 16u * (unsigned)lane; G.wsd = f32x2v{q.dy, q.dx}; G.wt = f32x2v{q.m, q.m}; return; }
         const int ul0 = 2 * jj, ul1 = 2 * jj + 1;
         const int t0 = f4_tap(ul0), t1 = f4_tap(ul1);
         const int ky0 = t0 / 3, kx0 = t0 % 3, ky1 = t1 / 3, kx1 = t1 % 3;
@@ -261,11 +276,35 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
         G.wsd = wy - G.wt;
     };
     auto corners = [&](float4 (&c)[8], const Fwd4Geo& G) {
+        if (ABL4 & 4) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = make_float4(G.wsd.x, G.wsd.y, G.wt.x, G.wt.y);
+            return;
+        }
         const float4* q0 = reinterpret_cast<const float4*>(smem_raw + G.addr);
         c[0] = q0[0]; c[1] = q0[NPOS]; c[2] = q0[1]; c[3] = q0[NPOS + 1];
         c[4] = q0[TC]; c[5] = q0[NPOS + TC]; c[6] = q0[TC + 1]; c[7] = q0[NPOS + TC + 1];
     };
     auto blend = [&](float (&v)[8], const float4 (&c)[8], const Fwd4Geo& G) {
+#ifdef RVSR_F4_SCALAR_BLEND   // (scratch variant: plain v_fma_f32 instead of the packed form -- packed f32 beside MFMAs is said to be expensive)
+        {
+            const float w00 = G.wsd.x, w10 = G.wsd.y, w01 = G.wt.x, w11 = G.wt.y;
+            auto b1 = [&](float a00, float a01, float a10, float a11) {
+                float r;
+                asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(w00), "v"(a00));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(r) : "v"(w01), "v"(a01));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(r) : "v"(w10), "v"(a10));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(r) : "v"(w11), "v"(a11));
+                return r;
+            };
+            v[0] = b1(c[0].x, c[2].x, c[4].x, c[6].x); v[1] = b1(c[0].y, c[2].y, c[4].y, c[6].y);
+            v[2] = b1(c[0].z, c[2].z, c[4].z, c[6].z); v[3] = b1(c[0].w, c[2].w, c[4].w, c[6].w);
+            v[4] = b1(c[1].x, c[3].x, c[5].x, c[7].x); v[5] = b1(c[1].y, c[3].y, c[5].y, c[7].y);
+            v[6] = b1(c[1].z, c[3].z, c[5].z, c[7].z); v[7] = b1(c[1].w, c[3].w, c[5].w, c[7].w);
+            return;
+        }
+#endif
+        if (ABL4 & 16) { v[0] = c[0].x; v[1] = c[1].x; v[2] = c[2].x; v[3] = c[3].x; v[4] = c[4].x; v[5] = c[5].x; v[6] = c[6].x; v[7] = c[7].x; return; }
         const f32x2v p0 = blend4v(G.wsd, G.wt, lo2v(c[0]), lo2v(c[2]), lo2v(c[4]), lo2v(c[6]));
         const f32x2v p1 = blend4v(G.wsd, G.wt, hi2v(c[0]), hi2v(c[2]), hi2v(c[4]), hi2v(c[6]));
         const f32x2v p2 = blend4v(G.wsd, G.wt, lo2v(c[1]), lo2v(c[3]), lo2v(c[5]), lo2v(c[7]));
@@ -277,12 +316,13 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = zero16();
     auto mma = [&](int slot, const bf16x8& bh, const bf16x8& bl) {
+        if (ABL4 & 1) { acc[0][0] += (float)bh[0] + (float)bl[1]; return; }
         const bf16x8* w = ws + slot * WSLOT + hi * MP + lo;
         bf16x8 ah[MT], al[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            ah[mt] = w[mt * 32];
-            al[mt] = w[2 * MP + mt * 32];
+            ah[mt] = (ABL4 & 2) ? bh : w[mt * 32];
+            al[mt] = (ABL4 & 2) ? bl : w[2 * MP + mt * 32];
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_bf16(ah[mt], bh, acc[mt]);
@@ -358,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
             float v[8];
             blend(v, cq, gC);
             // ---- barrier events: before the first corner read of the period's second chunk (jj == 3) / of the next period's first (jj == 8)
-            if (jj == 3 || jj == 8) {
+            if (!(ABL4 & 64) && (jj == 3 || jj == 8)) {
                 // The weight DMAs of the previous event must have landed.  VMEM reads return in order and at least twelve offset / mask
                 // requests (four k-steps) were issued after them, so "at most 9 operations outstanding" implies it -- without draining
                 // the requests of the next three k-steps (vmcnt(0) exposes one HBM round trip per event: measured 2-5 K cycles).
@@ -371,16 +411,33 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
             // ---- staging, trickled over the iterations after an event so that the eight waves' LDS stores and 16-byte loads do not
             // pile up behind the barrier: the registers hold the next period's first chunk at jj == 3 (slot xc), its second
             // chunk at jj == 8 (slot xa); they are refilled two iterations after their last store
-            if (jj == 3) x_write2(xv, xc, 0);
-            if (jj == 4) x_write2(xv, xc, 1);
-            if (jj == 8) x_write2(xv, xa, 0);
-            if (jj == 9) x_write2(xv, xa, 1);
-            if (jj == 5) x_load(xv, N, 1);
+            if (!(ABL4 & 64)) {
+                if (jj == 3) x_write2(xv, xc, 0);
+                if (jj == 4) x_write2(xv, xc, 1);
+                if (jj == 8) x_write2(xv, xa, 0);
+                if (jj == 9) x_write2(xv, xa, 1);
+                if (jj == 5) x_load(xv, N, 1);
+            }
             // ---- L(i+1): corner reads of k-step i+1
             corners(cq, gN);
             // ---- V2(i): bf16 hi / lo split of k-step i
             bf16x8 bh, bl;
-            split8(v, bh, bl);
+            if (ABL4 & 16) { bh = __builtin_bit_cast(bf16x8, make_float4(v[0], v[1], v[2], v[3])); bl = __builtin_bit_cast(bf16x8, make_float4(v[4], v[5], v[6], v[7])); }
+            else {
+#ifdef RVSR_F4_NODOT   // (scratch variant: lo = v - float(hi) through a shift / mask and a subtraction instead of v_dot2c_f32_bf16)
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    const bf2 h = {(__bf16)v[j], (__bf16)v[j + 1]};
+                    const unsigned hp = __builtin_bit_cast(unsigned, h);
+                    const float l0 = v[j] - __builtin_bit_cast(float, hp << 16), l1 = v[j + 1] - __builtin_bit_cast(float, hp & 0xffff0000u);
+                    bh[j] = h[0]; bh[j + 1] = h[1];
+                    bl[j] = (__bf16)l0; bl[j + 1] = (__bf16)l1;
+                }
+#else
+                split8(v, bh, bl);
+#endif
+            }
             // ---- M(i-1): the matrix core runs k-step i-1
             mma(jj - 1, bhP, blP);
             // ---- G(i+2): geometry of k-step i+2, requests of k-step i+5
@@ -390,6 +447,16 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
                 rqa = rqb; rqb = rqc;
                 if (j5 < 9) request(rqc, C, j5); else request(rqc, N, j5 - 9);
             }
+#ifdef RVSR_F4_SGB   // (scratch variant: ask the scheduler for one MFMA per RVSR_F4_SGB vector instructions (+ 2 LDS reads) instead of its clusters)
+#pragma unroll
+            for (int k = 0; k < 3 * MT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, RVSR_F4_SGB, 0);
+#ifdef RVSR_F4_SGB_DS
+                __builtin_amdgcn_sched_group_barrier(0x100, RVSR_F4_SGB_DS, 0);
+#endif
+            }
+#endif
             gC = gN; gN = gNN;
             bhP = bh; blP = bl;
 #ifdef RVSR_TIMELINE_DCN4
@@ -511,7 +578,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_fwd4_kernel(const Fwd4Params d, c
         if (C.per + 1 < nper) { N = C; N.per = C.per + 1; start_period(N); }
         else make_ctx(N, tile + 1 < t_end ? tile + 1 : tile, 0);
         // the staging registers were last stored from in iteration "jj == 9": refill them with the second period ahead's first chunk
-        x_load(xv, N, 0);
+        if (!(ABL4 & 64)) x_load(xv, N, 0);
     }
     TSTAMP4(58);
 }

@@ -1,0 +1,9 @@
+#!/bin/bash
+# timing ablations of dcn_fwd4 (scratch builds librealvsr_abl<bits>.so, tools/build_variant.sh; results wrong by construction)
+for ostd in 0.125 1.25; do
+  echo -n "ostd $ostd fwd3: "; RVSR_DCN_FWD=3 timeout 120 python tools/dcn_micro.py --B 40 --iters 20 --fwd-only --ostd $ostd 2>&1 | tail -1
+  echo -n "ostd $ostd fwd4: "; RVSR_DCN_FWD=4 timeout 120 python tools/dcn_micro.py --B 40 --iters 20 --fwd-only --ostd $ostd 2>&1 | tail -1
+  for b in "$@"; do
+    echo -n "ostd $ostd fwd4 variant $b: "; RVSR_SO=$PWD/realvsr_amd/csrc/librealvsr_$b.so RVSR_DCN_FWD=4 timeout 120 python tools/dcn_micro.py --B 40 --iters 20 --fwd-only --ostd $ostd 2>&1 | tail -1
+  done
+done
