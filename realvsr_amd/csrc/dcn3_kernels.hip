@@ -99,6 +99,14 @@ __device__ __forceinline__ f32x2 blend4(f32x2 s, f32x2 t, f32x2 a00, f32x2 a01, 
 // multiple of 4 for all three: tile rows start on 16-byte boundaries and the large tiles are staged with 16-byte loads.
 // TERMS: terms of the bf16 product (rvsr_common.h: gemm modes): 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part (that half of
 // the weight slice is not fetched); 1 = hi*hi (no lo part of the column values either)
+// Timing ablations of scratch builds (tools/build_variant.sh dcn3_kernels <name> -DRVSR_ABL3=<bits>; results wrong by construction):
+// 1 no MFMAs (nor weight-fragment reads), 4 no corner reads, 8 no far path, 16 no blend / split, 32 no offset / mask requests,
+// 64 no staging (x tile loads + stores, weight DMA; the barriers stay)
+#ifdef RVSR_ABL3
+constexpr int ABL3 = RVSR_ABL3;
+#else
+constexpr int ABL3 = 0;
+#endif
 template <int MT, int R, int TERMS = 3>
 __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_kernel(const DcnFwdParams p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
@@ -151,7 +159,8 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
         const unsigned off_lane = 4u * (pixc + (unsigned)(dg * 18) * (unsigned)hw), msk_lane = 4u * (pixc + (unsigned)(dg * 9) * (unsigned)hw);
         const unsigned off_pl = 4u * (unsigned)(g0 * 18) * (unsigned)hw, msk_pl = 4u * (unsigned)(g0 * 9) * (unsigned)hw, pl = 4u * (unsigned)hw;
         float n_dy = buf_load(off_rs, off_lane, off_pl), n_dx = buf_load(off_rs, off_lane, off_pl + pl), n_m = buf_load(msk_rs, msk_lane, msk_pl);
-        {   // weight slice + x tile of the chunk: ALL global loads first, then the LDS writes (one round trip)
+        if (ABL3 & 32) { n_dy = (float)lane * 1e-3f; n_dx = n_dy; n_m = 0.5f; }
+        if (!(ABL3 & 64) || chunk == 0) {   // weight slice + x tile of the chunk: ALL global loads first, then the LDS writes (one round trip)
             // weight slice: LDS-DMA (global_load_lds_dwordx4: lane l of a wave lands at M0 + 16 l, so a linear copy needs
             // no registers, no ds_write and no wait before the barrier's)
             const bf16x8* src = wpack + ((size_t)mb * nchunks + chunk) * 2 * WVEC;
@@ -222,7 +231,8 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
         for (int tap = 0; tap < 9; ++tap) {
             const float dy = n_dy, dx = n_dx;
             float m = n_m;
-            if (tap < 8) {  // (compile-time) prefetch the next tap's offsets/mask under this tap's math
+            if (ABL3 & 32) { n_dy = (float)lane * 1e-3f; n_dx = n_dy; n_m = 0.5f; }
+            else if (tap < 8) {  // (compile-time) prefetch the next tap's offsets/mask under this tap's math
                 n_dy = buf_load(off_rs, off_lane, off_pl + (unsigned)(2 * tap + 2) * pl);
                 n_dx = buf_load(off_rs, off_lane, off_pl + (unsigned)(2 * tap + 3) * pl);
                 n_m = buf_load(msk_rs, msk_lane, msk_pl + (unsigned)(tap + 1) * pl);
@@ -242,14 +252,19 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
             const f32x2 wy = {m - wy1, wy1};
             const f32x2 wt = wy * lx, wsd = wy - wt;
             const int pos = in_tile ? r0 * TC + s0 : 0;
-            const float4 a00 = xq0[pos], b00 = xq0[NPOS + pos], a01 = xq0[pos + 1], b01 = xq0[NPOS + pos + 1];
-            const float4 a10 = xq0[pos + TC], b10 = xq0[NPOS + pos + TC], a11 = xq0[pos + TC + 1], b11 = xq0[NPOS + pos + TC + 1];
+            float4 a00, b00, a01, b01, a10, b10, a11, b11;
+            if (ABL3 & 4) { a00 = make_float4(wsd.x, wsd.y, wt.x, wt.y); b00 = a01 = b01 = a10 = b10 = a11 = b11 = a00; }
+            else {
+                a00 = xq0[pos]; b00 = xq0[NPOS + pos]; a01 = xq0[pos + 1]; b01 = xq0[NPOS + pos + 1];
+                a10 = xq0[pos + TC]; b10 = xq0[NPOS + pos + TC]; a11 = xq0[pos + TC + 1]; b11 = xq0[NPOS + pos + TC + 1];
+            }
             const f32x2 p0 = blend4(wsd, wt, lo2(a00), lo2(a01), lo2(a10), lo2(a11));
             const f32x2 p1 = blend4(wsd, wt, hi2(a00), hi2(a01), hi2(a10), hi2(a11));
             const f32x2 p2 = blend4(wsd, wt, lo2(b00), lo2(b01), lo2(b10), lo2(b11));
             const f32x2 p3 = blend4(wsd, wt, hi2(b00), hi2(b01), hi2(b10), hi2(b11));
             float v[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
-            if (!in_tile && oct_ok) {
+            if (ABL3 & 16) { v[0] = a00.x; v[1] = b00.x; v[2] = a01.x; v[3] = b01.x; v[4] = a10.x; v[5] = b10.x; v[6] = a11.x; v[7] = b11.x; }
+            if (!(ABL3 & 8) && !in_tile && oct_ok) {
                 // large offset: this lane gathers its corners from global memory, with the reference's rules spelled out
                 // (image coordinates; kernel.cu:467-497,618)
 #pragma unroll
@@ -278,7 +293,9 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
                 }
             }
             bf16x8 bh, bl;
-            split8(v, bh, bl);
+            if (ABL3 & 16) { bh = __builtin_bit_cast(bf16x8, make_float4(v[0], v[1], v[2], v[3])); bl = __builtin_bit_cast(bf16x8, make_float4(v[4], v[5], v[6], v[7])); }
+            else split8(v, bh, bl);
+            if (ABL3 & 1) { acc[0][0] += (float)bh[0] + (float)bl[1]; continue; }
             bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
