@@ -148,6 +148,29 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
                            int channels_out, int stride, int pad, int dilation, int deformable_group,
                            const void* probe, void* workspace, size_t workspace_bytes, void* stream);
 
+/* 1c. The operator over its whole argument space: any kernel_h x kernel_w, anisotropic stride / padding / dilation, group >= 1, any
+ * number of channels per deformable group, DCNv1 (mask == NULL) and DCNv2, element types f32 / f64 / f16 (dtype 0 / 1 / 2) -- what
+ * modulated_deform_conv_cuda_forward / _backward and the three deform_conv_*_cuda functions accept (deform_conv_cuda.cpp:490-685,
+ * 152-488; AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:781).  Sections 1 / 1b / 1d are the fused f32 kernels for
+ * the geometries the reference's architectures instantiate (3 x 3, isotropic); this is the general path behind the same Python
+ * operator, organised as the reference organises it (per batch element: columns in the workspace + one GEMM per group).  All tensors
+ * of a call have the element type `dtype`; arithmetic is f32 for f16 / f32 tensors and f64 for f64.
+ *   backward: grad_input (zero on entry: scatter-add) and grad_offset are given together or both NULL; grad_mask NULL for DCNv1;
+ *   grad_weight / grad_bias are accumulated into, NULL = skip. */
+size_t rvsr_deform_conv_generic_workspace_bytes(int dtype, int channels, int height, int width, int kernel_h, int kernel_w,
+                                                int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w);
+int rvsr_deform_conv_generic_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
+                                     const void* mask, void* output, int batch, int channels, int height, int width,
+                                     int channels_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                                     int dilation_h, int dilation_w, int group, int deformable_group, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+int rvsr_deform_conv_generic_backward(int dtype, const void* input, const void* weight, const void* offset, const void* mask,
+                                      const void* grad_output, void* grad_input, void* grad_offset, void* grad_mask,
+                                      void* grad_weight, void* grad_bias, int batch, int channels, int height, int width,
+                                      int channels_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                                      int dilation_h, int dilation_w, int group, int deformable_group, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 2. Convolution blocks (nn.Conv2d 3x3 / 1x1, padding = ksize/2) with fused neighbours
  *    (EDVR_arch.py:96-132, 166-208, 256-319; arch_util.py:121-139)

@@ -51,11 +51,19 @@ def _suffix(t):
     raise TypeError('oracle DCN supports float32/float64, got %s' % t.dtype)
 
 
+def _hw(v):
+    """(h, w) of a geometry argument given as an int or a pair (the C restatement takes every component separately)."""
+    from torch.nn.modules.utils import _pair
+    a, b = _pair(v)
+    return int(a), int(b)
+
+
 def _geom(x, weight, stride, padding, dilation):
     kh, kw = weight.shape[2:4]
     H, W = x.shape[2:4]
-    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
-    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(padding), _hw(dilation)
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     return kh, kw, H, W, Ho, Wo
 
 
@@ -67,8 +75,9 @@ def im2col(x_b, off_b, msk_b, kh, kw, stride, padding, dilation, dg, Ho, Wo):
     C, H, W = x_b.shape
     col = torch.empty(C * kh * kw, Ho * Wo, dtype=x_b.dtype)
     fn = getattr(_lib(), 'oracle_modulated_im2col' + _suffix(x_b))
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(padding), _hw(dilation)
     fn(_ptr(x_b), _ptr(off_b), _ptr(msk_b),
-       *_ints(C, H, W, Ho, Wo, kh, kw, padding, padding, stride, stride, dilation, dilation, dg),
+       *_ints(C, H, W, Ho, Wo, kh, kw, ph, pw, sh, sw, dh, dw, dg),
        _ptr(col))
     return col
 
@@ -122,8 +131,8 @@ class ModulatedDeformConvOracle(torch.autograd.Function):
         gw = torch.zeros_like(weight)
         gb = torch.zeros(Co, dtype=x.dtype)
         cg, og = C // groups, Co // groups
-        geo = _ints(C, H, W, Ho, Wo, kh, kw, padding, padding, stride, stride, dilation,
-                    dilation, dg)
+        (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(padding), _hw(dilation)
+        geo = _ints(C, H, W, Ho, Wo, kh, kw, ph, pw, sh, sw, dh, dw, dg)
         for b in range(B):
             col_grad = torch.empty(C * K, Ho * Wo, dtype=x.dtype)
             for g in range(groups):  # cpp:623-626
@@ -162,11 +171,10 @@ def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1
     if input is not None and input.dim() != 4:
         raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
     (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
-    assert sh == sw and ph == pw and dh == dw, 'the C restatement takes isotropic geometry'
     cur = min(im2col_step, input.shape[0])
     assert input.shape[0] % cur == 0, 'im2col step must divide batchsize'
     kh, kw = weight.shape[2:]
     Ho = (input.shape[2] + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
     Wo = (input.shape[3] + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     mask = torch.ones(input.shape[0], deformable_groups * kh * kw, Ho, Wo, dtype=input.dtype)
-    return ModulatedDeformConvOracle.apply(input, offset, mask, weight, None, sh, ph, dh, groups, deformable_groups)
+    return ModulatedDeformConvOracle.apply(input, offset, mask, weight, None, (sh, sw), (ph, pw), (dh, dw), groups, deformable_groups)

@@ -14,7 +14,10 @@ checkpoints load with ``strict=True``.  The arithmetic runs in librealvsr_hip.so
 * DCNv1 (``deform_conv`` / ``DeformConv`` / ``DeformConvPack``, deform_conv.py:15-95,156-226): imported by no
   architecture in the reference; the reference's v1 kernels are its modulated kernels without the
   mask factor and without a bias (kernel.cu:190-465 vs :571-767), so the operator runs the same HIP kernels on a mask of
-  ones -> rvsr_deform_conv_{forward,backward_input,backward_parameters}.  Same geometry limits as the modulated operator.
+  ones -> rvsr_deform_conv_{forward,backward_input,backward_parameters}.
+* Every other geometry (kernel sizes other than 3 x 3, anisotropic stride / padding / dilation, groups, channels per deformable group that
+  neither divide nor are a multiple of 8) and the element types f64 / f16 run on the operator's general path (csrc/dcn_generic.hip,
+  rvsr_deform_conv_generic_{forward,backward}): columns + GEMM per batch element, as the reference computes every call.
 """
 import math
 
@@ -24,6 +27,20 @@ from torch.nn.modules.utils import _pair
 
 from ... import functional as RF
 from ...functional import DeformConvFunction, ModulatedDeformConvFunction, deform_conv, modulated_deform_conv
+
+
+def _offset_conv(x, conv):
+    """The pack's offset convolution.  3 x 3 / padding 1 / isotropic stride: the fused conv kernel.  Any other geometry (the conv has the
+    DCN's own kernel size, stride and padding, deform_conv.py:212-217, 262-268): the general deformable path with ZERO offsets, which is that
+    convolution exactly (every sample falls on a pixel centre)."""
+    k, st, pd, dl = _pair(conv.kernel_size), _pair(conv.stride), _pair(conv.padding), _pair(conv.dilation)
+    if k == (3, 3) and pd == (1, 1) and dl == (1, 1) and st[0] == st[1] and st[0] in (1, 2) and conv.groups == 1 and x.dtype == torch.float32:
+        return RF.conv2d(x, conv)
+    Ho = (x.shape[2] + 2 * pd[0] - (dl[0] * (k[0] - 1) + 1)) // st[0] + 1
+    Wo = (x.shape[3] + 2 * pd[1] - (dl[1] * (k[1] - 1) + 1)) // st[1] + 1
+    zero = x.new_zeros(x.shape[0], 2 * k[0] * k[1], Ho, Wo)
+    out = deform_conv(x, zero, conv.weight, st, pd, dl, conv.groups, 1)
+    return out if conv.bias is None else out + conv.bias.view(1, -1, 1, 1)
 
 
 class DeformConv(nn.Module):
@@ -56,11 +73,8 @@ class DeformConvPack(DeformConv):
         self.conv_offset.bias.data.zero_()
 
     def forward(self, x):
-        # (deform_conv.py:222-226) conv_offset is an ordinary convolution with the DCN's own kernel size / stride / padding: the fused
-        # conv kernel covers what the HIP deformable kernels cover (3x3, padding 1, isotropic stride)
-        if self.kernel_size != (3, 3) or self.padding != (1, 1) or self.stride[0] != self.stride[1]:
-            raise RuntimeError('DeformConvPack: only 3x3 / padding 1 / isotropic stride is implemented on the HIP path')
-        offset = RF.conv2d(x, self.conv_offset)
+        # (deform_conv.py:222-226) conv_offset is an ordinary convolution with the DCN's own kernel size / stride / padding
+        offset = _offset_conv(x, self.conv_offset)
         return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
                            self.deformable_groups)
 
@@ -136,8 +150,12 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
             o1, o2, mask = torch.chunk(out, 3, dim=1)
             return modulated_deform_conv(x, torch.cat((o1, o2), dim=1), torch.sigmoid(mask), self.weight, self.bias, self.stride,
                                          self.padding, self.dilation, self.groups, self.deformable_groups)
-        # Everything the reference's architectures instantiate (EDVR_arch.py:73-74, TDAN_arch.py:29-41) is 3x3, groups=1,
-        # "same" padding.  Other kernel sizes have no HIP kernel here and there is deliberately no library fallback.
-        raise RuntimeError('ModulatedDeformConvPack: only 3x3 / padding=dilation is implemented on the '
-                           'MI355X path (got kernel %s, groups %d, padding %s, dilation %s)'
-                           % (self.kernel_size, self.groups, self.padding, self.dilation))
+        # Everything the reference's architectures instantiate (EDVR_arch.py:73-74, TDAN_arch.py:29-41) is 3x3, groups=1, "same" padding and
+        # runs on the fused kernels above.  Any other geometry: the reference's wiring (deform_conv.py:284-292) on the operator's general path
+        # (csrc/dcn_generic.hip), without the fusion extensions.
+        if act != RF.ACT_NONE or sink is not None:
+            raise RuntimeError('ModulatedDeformConvPack: act / sink are extensions of the fused 3x3 / groups=1 path')
+        out = _offset_conv(feat, self.conv_offset_mask)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        return modulated_deform_conv(x, torch.cat((o1, o2), dim=1), torch.sigmoid(mask), self.weight, self.bias, self.stride,
+                                     self.padding, self.dilation, self.groups, self.deformable_groups)

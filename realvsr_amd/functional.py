@@ -28,7 +28,8 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _need_cuda(*ts):
+def _need_cuda(*ts, any_float=False):
+    """any_float: the deformable operators also take f64 / f16 tensors (their general path), everything else is float32."""
     dev = None
     for t in ts:
         if t is None:
@@ -36,7 +37,7 @@ def _need_cuda(*ts):
         if not t.is_cuda:
             raise NotImplementedError('realvsr_amd operators run on MI355X (HIP) tensors only; got a %s tensor'
                                       % t.device.type)
-        if t.dtype != torch.float32:
+        if t.dtype != torch.float32 and not (any_float and t.dtype in (torch.float64, torch.float16)):
             raise TypeError('realvsr_amd operators are float32 (like the reference training path); got %s' % t.dtype)
         if dev is None:
             dev = t.device
@@ -681,6 +682,92 @@ class DcnOffsetStats:
 dcn_offset_stats = DcnOffsetStats()
 
 
+# ---- the general path of the deformable operator (include/realvsr_hip.h section 1c, csrc/dcn_generic.hip): any kernel size, anisotropic
+# stride / padding / dilation, groups, any channels per deformable group, f32 / f64 / f16.  The fused kernels take the calls they cover.
+_GENERIC_DTYPES = {torch.float32: 0, torch.float64: 1, torch.float16: 2}
+
+
+def _pair2(v):
+    from torch.nn.modules.utils import _pair
+    a, b = _pair(v)
+    return int(a), int(b)
+
+
+def _dcn_fused_ok(input, weight, stride, padding, dilation, groups, dg):
+    """Whether the fused f32 kernels cover this call: 3 x 3, isotropic geometry, one group, channels per deformable group a multiple or a
+    divisor of 8 (dcn_kernels.hip fill_geom)."""
+    (sh, sw), (ph, pw), (dh, dw) = _pair2(stride), _pair2(padding), _pair2(dilation)
+    C = input.shape[1]
+    if input.dtype != torch.float32 or tuple(weight.shape[2:]) != (3, 3) or sh != sw or ph != pw or dh != dw or groups != 1:
+        return False
+    if dg <= 0 or C % dg:
+        return False
+    cpg = C // dg
+    return cpg % 8 == 0 or 8 % cpg == 0
+
+
+def _generic_geom(input, weight, stride, padding, dilation):
+    (sh, sw), (ph, pw), (dh, dw) = _pair2(stride), _pair2(padding), _pair2(dilation)
+    B, C, H, W = input.shape
+    Co, _, kh, kw = weight.shape
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    return (B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw), Ho, Wo
+
+
+def _generic_check(input, offset, mask, weight, bias, groups, dg, Ho, Wo):
+    dt = _GENERIC_DTYPES.get(input.dtype)
+    if dt is None:
+        raise TypeError('deformable convolution: element type %s (f32, f64 and f16 are implemented)' % input.dtype)
+    B, C = input.shape[:2]
+    Co, cg, kh, kw = weight.shape
+    for name, t in (('offset', offset), ('mask', mask), ('weight', weight), ('bias', bias)):
+        if t is not None and t.dtype != input.dtype:
+            raise TypeError('deformable convolution: %s is %s, input is %s' % (name, t.dtype, input.dtype))
+    if C % groups or Co % groups or cg * groups != C:
+        raise RuntimeError('deformable convolution: channels (%d -> %d, weight %s) not divisible into %d groups' % (C, Co, tuple(weight.shape), groups))
+    if dg <= 0 or C % dg:
+        raise RuntimeError('deformable convolution: %d input channels not divisible into %d deformable groups' % (C, dg))
+    if Ho <= 0 or Wo <= 0:
+        raise ValueError('convolution input is too small (output would be %dx%d)' % (Ho, Wo))
+    if tuple(offset.shape) != (B, 2 * dg * kh * kw, Ho, Wo):
+        raise RuntimeError('deformable convolution: offset has shape %s, expected %s' % (tuple(offset.shape), (B, 2 * dg * kh * kw, Ho, Wo)))
+    if mask is not None and tuple(mask.shape) != (B, dg * kh * kw, Ho, Wo):
+        raise RuntimeError('deformable convolution: mask has shape %s, expected %s' % (tuple(mask.shape), (B, dg * kh * kw, Ho, Wo)))
+    return dt
+
+
+def _generic_dcn_forward(input, offset, mask, weight, bias, stride, padding, dilation, groups, dg):
+    geo, Ho, Wo = _generic_geom(input, weight, stride, padding, dilation)
+    dt = _generic_check(input, offset, mask, weight, bias, groups, dg, Ho, Wo)
+    input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    out = input.new_empty(input.shape[0], weight.shape[0], Ho, Wo)
+    L = _lib.lib()
+    ws = _workspace(L.rvsr_deform_conv_generic_workspace_bytes(dt, *geo[1:4], *geo[5:]), input.device)
+    _lib.check(L.rvsr_deform_conv_generic_forward(dt, _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(out), *geo, groups, dg,
+                                                  _p(ws), ws.numel(), _stream()), 'deform_conv_generic_forward')
+    return out
+
+
+def _generic_dcn_backward(input, offset, mask, weight, grad_output, stride, padding, dilation, groups, dg, need_input, need_weight, with_bias):
+    geo, Ho, Wo = _generic_geom(input, weight, stride, padding, dilation)
+    dt = _GENERIC_DTYPES[input.dtype]
+    input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    gx = torch.zeros_like(input) if need_input else None
+    goff = torch.empty_like(offset) if need_input else None
+    gmask = torch.empty_like(mask) if (need_input and mask is not None) else None
+    gw = torch.zeros_like(weight) if need_weight else None
+    gb = weight.new_zeros(weight.shape[0]) if with_bias else None
+    L = _lib.lib()
+    ws = _workspace(L.rvsr_deform_conv_generic_workspace_bytes(dt, *geo[1:4], *geo[5:]), input.device)
+    _lib.check(L.rvsr_deform_conv_generic_backward(dt, _p(input), _p(weight), _p(offset), _p(mask), _p(grad_output), _p(gx), _p(goff), _p(gmask),
+                                                   _p(gw), _p(gb), *geo, groups, dg, _p(ws), ws.numel(), _stream()), 'deform_conv_generic_backward')
+    return gx, goff, gmask, gw, gb
+
+
 class ModulatedDeformConvFunction(Function):
     """Same signature and semantics as the reference's autograd Function
     (codes/models/archs/dcn/deform_conv.py:97-153)."""
@@ -690,12 +777,18 @@ class ModulatedDeformConvFunction(Function):
                 deformable_groups=1):
         if not input.is_cuda:
             raise NotImplementedError
-        _need_cuda(input, offset, mask, weight, bias)
+        _need_cuda(input, offset, mask, weight, bias, any_float=True)
         if not input.is_contiguous():
             raise RuntimeError('input tensor has to be contiguous')      # deform_conv_cuda.cpp:497
         if not weight.is_contiguous():
             raise RuntimeError('weight tensor has to be contiguous')     # deform_conv_cuda.cpp:498
         offset, mask = offset.contiguous(), mask.contiguous()
+        ctx.cfg = (stride, padding, dilation, groups, deformable_groups, bias is not None)
+        ctx.generic = not _dcn_fused_ok(input, weight, stride, padding, dilation, groups, deformable_groups)
+        if ctx.generic:   # any kernel size / anisotropic geometry / groups / f64, f16: the general path (realvsr_hip.h section 1c)
+            ctx.save_for_backward(input, offset, mask, weight, bias)
+            return _generic_dcn_forward(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups)
+        stride, padding, dilation = _pair2(stride)[0], _pair2(padding)[0], _pair2(dilation)[0]   # (isotropic here; pairs are accepted)
         ctx.cfg = (stride, padding, dilation, groups, deformable_groups, bias is not None)
         B, C, H, W = input.shape
         Co, _, kh, kw = weight.shape
@@ -719,6 +812,10 @@ class ModulatedDeformConvFunction(Function):
             raise NotImplementedError
         input, offset, mask, weight, bias = ctx.saved_tensors
         stride, padding, dilation, groups, dg, with_bias = ctx.cfg
+        if ctx.generic:
+            gx, goff, gmask, gw, gb = _generic_dcn_backward(input, offset, mask, weight, grad_output, stride, padding, dilation, groups, dg, True, True,
+                                                            with_bias)
+            return gx, goff, gmask, gw, gb, None, None, None, None, None
         grad_output = grad_output.contiguous()
         B, C, H, W = input.shape
         Co, _, kh, kw = weight.shape
@@ -748,6 +845,10 @@ def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padd
     if not input.is_cuda:
         raise NotImplementedError
     C, Co, dg = input.shape[1], weight.shape[0], deformable_groups
+    slices_fused = (C % groups == 0 and (dg % groups == 0 or groups % dg == 0) and
+                    _dcn_fused_ok(input[:, :C // groups], weight, stride, padding, dilation, 1, max(dg // groups, 1)))
+    if not slices_fused:   # (the general path takes groups as the reference does: one GEMM per group on the shared columns)
+        return ModulatedDeformConvFunction.apply(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups)
     K = weight.shape[2] * weight.shape[3]
     if C % groups or Co % groups or weight.shape[1] * groups != C:
         raise RuntimeError('modulated_deform_conv: channels (%d -> %d) not divisible into %d groups' % (C, Co, groups))
@@ -782,13 +883,16 @@ class DeformConvFunction(Function):
         out_size = DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
         if not input.is_cuda:
             raise NotImplementedError
-        _need_cuda(input, offset, weight)
+        _need_cuda(input, offset, weight, any_float=True)
         cur = min(im2col_step, input.shape[0])
         assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
         input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()   # deform_conv_cuda.cpp:170-172
         if offset.shape[0] != input.shape[0]:
             raise RuntimeError('invalid batch size of offset')                               # deform_conv_cuda.cpp:193
         ctx.save_for_backward(input, offset, weight)
+        ctx.generic = not _dcn_fused_ok(input, weight, ctx.stride, ctx.padding, ctx.dilation, groups, deformable_groups)
+        if ctx.generic:   # the general path (realvsr_hip.h section 1c): mask == NULL is DCNv1
+            return _generic_dcn_forward(input, offset, None, weight, None, ctx.stride, ctx.padding, ctx.dilation, groups, deformable_groups)
         output = input.new_empty(out_size)
         DeformConvFunction._call('rvsr_deform_conv_forward', ctx, input, weight, cur, [input, weight, offset, output], [])
         return output
@@ -813,6 +917,11 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         cur = min(ctx.im2col_step, input.shape[0])
         grad_output = grad_output.contiguous()
+        if ctx.generic:
+            gx, goff, _, gw, _ = _generic_dcn_backward(input, offset, None, weight, grad_output, ctx.stride, ctx.padding, ctx.dilation, ctx.groups,
+                                                       ctx.deformable_groups, ctx.needs_input_grad[0] or ctx.needs_input_grad[1],
+                                                       ctx.needs_input_grad[2], False)
+            return gx, goff, gw, None, None, None, None, None, None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
             DeformConvFunction._call('rvsr_deform_conv_backward_input', ctx, input, weight, cur,

@@ -149,9 +149,12 @@ def test_errors():
         modulated_deform_conv(torch.randn(1, 8, 4, 4), torch.zeros(1, 18, 4, 4), torch.ones(1, 9, 4, 4),
                               torch.randn(8, 8, 3, 3), None, 1, 1, 1, 1, 1)
     d = dev()
-    with pytest.raises(RuntimeError):  # 5x5 kernels are not on the HIP path: loud, not silent
-        modulated_deform_conv(torch.randn(1, 8, 8, 8, device=d), torch.zeros(1, 50, 8, 8, device=d),
-                              torch.ones(1, 25, 8, 8, device=d), torch.randn(8, 8, 5, 5, device=d), None, 1, 2, 1, 1, 1)
+    # a 5 x 5 kernel: the operator's general path (tests/test_gpu_dcn_generic.py); zero offsets and a unit mask make it the plain convolution
+    x5, w5 = torch.randn(1, 8, 8, 8, device=d), torch.randn(8, 8, 5, 5, device=d)
+    out5 = modulated_deform_conv(x5, torch.zeros(1, 50, 8, 8, device=d), torch.ones(1, 25, 8, 8, device=d), w5, None, 1, 2, 1, 1, 1)
+    check('5x5, zero offsets == conv2d', out5, torch.nn.functional.conv2d(x5.double().cpu(), w5.double().cpu(), None, padding=2), 2e-5)
+    with pytest.raises(RuntimeError):  # an offset tensor of the wrong shape: loud, not silent
+        modulated_deform_conv(x5, torch.zeros(1, 18, 8, 8, device=d), torch.ones(1, 25, 8, 8, device=d), w5, None, 1, 2, 1, 1, 1)
     with pytest.raises(RuntimeError):  # non-contiguous input, as deform_conv_cuda.cpp:497
         modulated_deform_conv(torch.randn(1, 8, 8, 16, device=d)[:, :, :, ::2], torch.zeros(1, 18, 8, 8, device=d),
                               torch.ones(1, 9, 8, 8, device=d), torch.randn(8, 8, 3, 3, device=d), None, 1, 1, 1, 1, 1)

@@ -69,5 +69,9 @@ def test_v1_modules_and_errors(gemm_mode):
         deform_conv(torch.randn(1, 8, 4, 4), torch.zeros(1, 18, 4, 4), torch.randn(8, 8, 3, 3))
     with pytest.raises(AssertionError):   # im2col_step must divide the batch (deform_conv.py:41)
         deform_conv(torch.randn(3, 8, 8, 8, device=d), torch.zeros(3, 18, 8, 8, device=d), torch.randn(8, 8, 3, 3, device=d), 1, 1, 1, 1, 1, 2)
-    with pytest.raises(RuntimeError):     # 5x5 kernels are not on the HIP path: loud, not silent
-        deform_conv(torch.randn(1, 8, 8, 8, device=d), torch.zeros(1, 50, 8, 8, device=d), torch.randn(8, 8, 5, 5, device=d), 1, 2, 1, 1, 1)
+    # a 5 x 5 kernel: the operator's general path (tests/test_gpu_dcn_generic.py); zero offsets make it the plain convolution
+    x5, w5 = torch.randn(1, 8, 8, 8, device=d), torch.randn(8, 8, 5, 5, device=d)
+    check('5x5 DCNv1, zero offsets == conv2d', deform_conv(x5, torch.zeros(1, 50, 8, 8, device=d), w5, 1, 2, 1, 1, 1),
+          F.conv2d(x5.double().cpu(), w5.double().cpu(), None, padding=2), 2e-5)
+    with pytest.raises(RuntimeError):     # an offset tensor of the wrong shape: loud, not silent
+        deform_conv(x5, torch.zeros(1, 18, 8, 8, device=d), w5, 1, 2, 1, 1, 1)

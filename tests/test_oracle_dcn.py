@@ -120,3 +120,27 @@ def test_v1_f64_finite_differences():
     w = torch.randn(Co, C, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
     fn = lambda *a: deform_conv(*a, 1, 1, 1, 1, dg)  # noqa: E731
     assert torch.autograd.gradcheck(fn, (x, off, w), eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
+def test_generic_geometry_zero_offsets_is_grouped_conv2d_and_f64_finite_differences():
+    """The oracle over the operator's whole geometry space (2 x 3 kernel, anisotropic stride / padding / dilation, 2 groups, 2 deformable
+    groups): with zero offsets and a unit mask it is torch's grouped conv2d; its gradients pass f64 finite differences."""
+    g = torch.Generator().manual_seed(7)
+    B, C, Co, H, W, groups, dg = 2, 4, 6, 7, 8, 2, 2
+    kh, kw, stride, pad, dil = 2, 3, (2, 1), (1, 0), (1, 2)
+    Ho = (H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Co, C // groups, kh, kw, generator=g, dtype=torch.float64)
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    off0 = torch.zeros(B, dg * 2 * kh * kw, Ho, Wo, dtype=torch.float64)
+    m1 = torch.ones(B, dg * kh * kw, Ho, Wo, dtype=torch.float64)
+    out = modulated_deform_conv(x, off0, m1, w, b, stride, pad, dil, groups, dg)
+    assert rel_err(out, F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil, groups=groups)) < 1e-12
+    off = (torch.rand(B, dg * 2 * kh * kw, Ho, Wo, generator=g, dtype=torch.float64) - 0.5) * 1.6 + 0.05
+    m = torch.rand(B, dg * kh * kw, Ho, Wo, generator=g, dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (x, off, m, w, b)]
+
+    def fn(x_, o_, m_, w_, b_):
+        return modulated_deform_conv(x_, o_, m_, w_, b_, stride, pad, dil, groups, dg)
+    assert torch.autograd.gradcheck(fn, leaves, eps=1e-6, atol=1e-6, rtol=1e-5)
