@@ -9,7 +9,7 @@ import re
 import shutil
 
 SRC, DST = 'gpurun_out/r04_profiles', 'profiles'
-for name in ['bench_default.json', 'offsets_3px.json', 'bench_c3.json', 'infer_c5.json', 'default_kernel_stats.csv', 'c3_kernel_stats.csv']:
+for name in ['bench_default.json', 'offsets_3px.json', 'bench_c3.json', 'infer_c5.json', 'default_kernel_stats.csv', 'c3_kernel_stats.csv', 'bf16_mode_kernel_stats.csv']:
     src = os.path.join(SRC, name)
     if not os.path.exists(src):
         continue

@@ -11,6 +11,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- pytho
 cp "$(find $O/prof_default -name '*kernel_stats.csv' | head -1)" $O/default_kernel_stats.csv; rm -rf $O/prof_default
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -- python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-sweep --no-extra > $O/prof_c3.json 2>/dev/null
 cp "$(find $O/prof_c3 -name '*kernel_stats.csv' | head -1)" $O/c3_kernel_stats.csv; rm -rf $O/prof_c3
+RVSR_GEMM=bf16 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --no-extra > $O/prof_bf16.json 2>/dev/null
+cp "$(find $O/prof_bf16 -name '*kernel_stats.csv' | head -1)" $O/bf16_mode_kernel_stats.csv; rm -rf $O/prof_bf16
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
 P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"
 P3="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"
