@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
                 ah[mt] = ws_hi[(tap * 2 + hi) * MP + mt * 32 + lo];
                 if (TERMS >= 3) al[mt] = ws_lo[(tap * 2 + hi) * MP + mt * 32 + lo];
             }
-#ifdef RVSR_F3_PRIO   // (scratch variant, tools/build_variant_f3.sh: priority of the wave while it feeds the matrix core)
+#ifdef RVSR_F3_PRIO   // (scratch variant, tools/build_variant.sh dcn3_kernels <name> -DRVSR_F3_PRIO: priority of the wave while it feeds the matrix core)
             __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll

@@ -1,5 +1,5 @@
 """s_memtime timeline of one dcn_fwd4_kernel workgroup, per wave (build: TLFLAGS=-DRVSR_TIMELINE_DCN4 tools/build_timeline.sh;
-run with RVSR_SO=$PWD/realvsr_amd/csrc/librealvsr_tl.so python tools/dcn4_timeline.py [offset std])."""
+run with RVSR_DCN_FWD=4 RVSR_SO=$PWD/realvsr_amd/csrc/librealvsr_tl.so python tools/dcn4_timeline.py [offset std])."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from realvsr_amd import functional as RF
@@ -14,9 +14,9 @@ for _ in range(3):
 torch.cuda.synchronize()
 L = ctypes.CDLL(os.environ['RVSR_SO'])
 buf = (ctypes.c_ulonglong * 1024)()
-print('rc', L.rvsr_debug_read_dcn4(buf), 'offset std', ostd, 'dbg', os.environ.get('RVSR_DCN4_DBG'))
+print('rc', L.rvsr_debug_read_dcn4(buf), 'offset std', ostd)
 t = list(buf)
-nw = int(os.environ.get('RVSR_DCN4_NW', '8'))
+nw = 8   # waves per workgroup (Fwd4<8, 5, 7, MT>)
 t0 = min(t[w * 64] for w in range(nw) if t[w * 64])
 for w in range(nw):
     s = t[w * 64:(w + 1) * 64]
