@@ -151,7 +151,7 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
 /* 1c. The operator over its whole argument space: any kernel_h x kernel_w, anisotropic stride / padding / dilation, group >= 1, any
  * number of channels per deformable group, DCNv1 (mask == NULL) and DCNv2, element types f32 / f64 / f16 (dtype 0 / 1 / 2) -- what
  * modulated_deform_conv_cuda_forward / _backward and the three deform_conv_*_cuda functions accept (deform_conv_cuda.cpp:490-685,
- * 152-488; AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:781).  Sections 1 / 1b / 1d are the fused f32 kernels for
+ * 152-488; AT_DISPATCH_FLOATING_TYPES_AND_HALF, deform_conv_cuda_kernel.cu:781).  Sections 1 / 1b above are the fused f32 kernels for
  * the geometries the reference's architectures instantiate (3 x 3, isotropic); this is the general path behind the same Python
  * operator, organised as the reference organises it (per batch element: columns in the workspace + one GEMM per group).  All tensors
  * of a call have the element type `dtype`; arithmetic is f32 for f16 / f32 tensors and f64 for f64.
