@@ -175,3 +175,49 @@ def test_config2_window_holds_the_north_star_psnr_bound(mode):
     # a trained network's residual branch is O(0.05) of the [0, 1] range: even then this error moves a 30 dB PSNR by
     # 4.34 * (res_err * 0.05 / 10^-1.5)^2 dB
     assert 4.34 * (res_err * 0.05 / 10 ** -1.5) ** 2 <= 1e-3
+
+
+def test_training_steps_in_the_speed_modes_track_the_default_mode(speed_mode):
+    """Three optimizer steps of VideoSRModel (EDVR nf64: the 64-row kernels the modes act in) from the same initial state: the per-step
+    losses of a speed mode follow the three-term mode's to ~1e-6 (Adam's sign-like first updates amplify gradient differences in the
+    parameters themselves, so those are only bounded loosely)."""
+    from realvsr_amd import _lib
+    from realvsr_amd.VideoSR_model import create_model
+    net = dict(which_model_G='EDVR', nf=64, nc=3, nframes=3, groups=8, front_RBs=2, back_RBs=2, center=None, predeblur=False, HR_in=False,
+               w_TSA=True)
+    opt = {'model': 'VideoSR_AllPair_YCbCr_Split', 'dist': False, 'gpu_ids': [0], 'is_train': True, 'scale': 4, 'augment': None,
+           'network_G': net, 'path': {'pretrain_model_G': None, 'strict_load': True},
+           'train': {'pixel_criterion_y': 'lappyr', 'pixel_weight_y': 1.0, 'pixel_criterion_c': 'gw', 'pixel_weight_c': 0.5,
+                     'weight_decay_G': 0, 'ft_tsa_only': 0, 'lr_G': 1e-4, 'beta1': 0.9, 'beta2': 0.99}}
+    g = torch.Generator().manual_seed(21)
+    data = {'LQs': torch.rand(2, 3, 3, 32, 64, generator=g), 'GT': torch.rand(2, 3, 3, 128, 256, generator=g)}
+
+    def run(mode):
+        _lib.set_gemm_mode(mode)
+        torch.manual_seed(5)
+        model = create_model(opt)
+        with torch.no_grad():
+            for name, p in model.netG.named_parameters():
+                if 'conv_offset_mask.weight' in name:
+                    p.normal_(0, 0.01, generator=torch.Generator(device=p.device).manual_seed(len(name)))
+        from realvsr_amd import functional as RF
+        RF.invalidate_weight_cache()
+        start = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+        losses = []
+        for step in range(1, 4):
+            model.feed_data(data)
+            model.optimize_parameters(step)
+            losses.append(model.get_current_log()['l_pix'])
+        upd = torch.cat([(v.detach() - start[k]).flatten() for k, v in model.netG.state_dict().items()])
+        return losses, upd
+    try:
+        l_ref, u_ref = run('bf16x3')
+        l_got, u_got = run(speed_mode)
+    finally:
+        _lib.set_gemm_mode(speed_mode)   # (the fixture restores the caller's mode)
+    print(speed_mode, 'losses', l_got, 'three-term', l_ref)
+    for a, b in zip(l_got, l_ref):
+        assert abs(a - b) <= 1e-4 * abs(b), (l_got, l_ref)   # (measured: 1e-6)
+    rel = float((u_got - u_ref).norm() / u_ref.norm())
+    print('parameter update after 3 steps: rel l2 difference %.3f' % rel)
+    assert rel <= 0.2 and torch.isfinite(u_got).all()   # (measured: 0.09)
