@@ -510,8 +510,8 @@ def infer_line(a, T=10, offset_px=None):
            'graph_bit_identical': bool(torch.equal(out, out_g)),
            'dcn_fwd_frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
            'dcn_fwd_avg_launch_ms': round(kms / max(nl, 1), 4), 'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3),
-           'note': 'the eager pass is GPU-bound at this frame size (no launch gaps), so the hipGraph replay of the window stage has '
-                   'nothing to recover and pays for gathering the window into static buffers',
+           'note': 'hipGraph path: a ring of N feature slots (one slot overwritten per frame) + one captured graph per rotation of the ring, '
+                   'replayed round-robin; the eager pass is GPU-bound at this frame size (no launch gaps), so the replay has nothing to recover',
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     from realvsr_amd import _lib as rlib
     if rlib.get_gemm_mode() == 'bf16x3':   # the opt-in speed mode on the same clip (eager)

@@ -90,41 +90,46 @@ class SlidingWindowRunner(object):
     """
 
     def __init__(self, net, N, padding='replicate', chunk=8, flip_ensemble=False, use_graph=False):
-        """use_graph: capture the window stage (alignment + fusion + reconstruction of one output frame) once per clip
-        geometry as a hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture; every kernel of the path is a plain
-        launch on the capturing stream) and replay it per frame from static input buffers -- BASELINE config 5 asks
-        for a graph-captured sliding window; it matters for small frames, which are launch-bound."""
+        """use_graph: run the window stage (alignment + fusion + reconstruction of one output frame) as hipGraph replays
+        (torch.cuda.CUDAGraph drives hipStreamBeginCapture; every kernel of the path is a plain launch on the capturing stream) --
+        BASELINE config 5 asks for a graph-captured sliding window; it matters for small frames, which are launch-bound.  The
+        features of the N frames of a window live in a RING of N static slots: consecutive windows share N - 1 frames, so a step
+        overwrites one slot (the entering frame; at a clip's ends whatever the padding mode changes) instead of gathering the whole
+        window, and the window's frame order is a rotation of the ring -- one captured graph per rotation (N graphs, captured on
+        first use, sharing one memory pool), replayed round-robin."""
         if N // 2 != net.center:
             raise RuntimeError('window of %d frames does not match the network centre %d' % (N, net.center))
         self.net, self.N, self.padding, self.chunk, self.flip = net, N, padding, chunk, flip_ensemble
         self.use_graph = use_graph
-        self._graph = None      # (key, graph, static inputs, static output)
+        self._ring = None       # graph mode: {key, slots s1 / s2 / s3, centre-frame buffer sx, graphs: rotation -> (graph, output), pool}
 
-    def _window_graph(self, L1, L2, L3, frame):
-        """Capture align_fuse_reconstruct for windows shaped like (N x L1[0], ..., frame); returns the replay closure."""
+    def _ring_state(self, L1, L2, L3, frame):
         key = (tuple(L1.shape[1:]), tuple(frame.shape), L1.device.index)
-        if self._graph is None or self._graph[0] != key:
+        if self._ring is None or self._ring['key'] != key:
             N = self.N
-            s1 = L1.new_empty((N,) + tuple(L1.shape[1:]))
-            s2 = L2.new_empty((N,) + tuple(L2.shape[1:]))
-            s3 = L3.new_empty((N,) + tuple(L3.shape[1:]))
-            sx = frame.new_empty(frame.shape)
-            for t in (s1, s2, s3, sx):
-                t.zero_()
+            slots = [f.new_zeros((N,) + tuple(f.shape[1:])) for f in (L1, L2, L3)]
+            self._ring = {'key': key, 'slots': slots, 'sx': frame.new_zeros(frame.shape), 'graphs': {}, 'pool': torch.cuda.graph_pool_handle()}
+        return self._ring
+
+    def _ring_graph(self, ring, r):
+        """The window stage on the ring rotated by r: frame j of the window is slot (r + j) % N."""
+        if r not in ring['graphs']:
+            N, (s1, s2, s3), sx = self.N, ring['slots'], ring['sx']
+            order = [(r + j) % N for j in range(N)]
 
             def stage():
-                return self.net.align_fuse_reconstruct([s1[j:j + 1] for j in range(N)], [s2[j:j + 1] for j in range(N)],
-                                                       [s3[j:j + 1] for j in range(N)], sx)
+                return self.net.align_fuse_reconstruct([s1[k:k + 1] for k in order], [s2[k:k + 1] for k in order],
+                                                       [s3[k:k + 1] for k in order], sx)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):   # warm-up on the capture stream: sizes the scratch workspace
                 stage()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with torch.cuda.graph(graph, stream=side, pool=ring['pool']):
                 out = stage()
-            self._graph = (key, graph, (s1, s2, s3, sx), out)
-        return self._graph
+            ring['graphs'][r] = (graph, out)
+        return ring['graphs'][r]
 
     def _features(self, clip):
         feats = [[], [], []]
@@ -138,15 +143,20 @@ class SlidingWindowRunner(object):
         L1, L2, L3 = self._features(clip)
         outs = []
         if self.use_graph:
-            _, graph, (s1, s2, s3, sx), gout = self._window_graph(L1, L2, L3, clip[0:1])
+            ring = self._ring_state(L1, L2, L3, clip[0:1])
+            held = [None] * self.N      # which frame each ring slot holds
         for t in range(T):
             idx = index_generation(t, T, self.N, self.padding)
             if self.use_graph:
-                sel = torch.tensor(idx, device=clip.device)
-                torch.index_select(L1, 0, sel, out=s1)
-                torch.index_select(L2, 0, sel, out=s2)
-                torch.index_select(L3, 0, sel, out=s3)
-                sx.copy_(clip[t:t + 1])
+                r = t % self.N
+                for j, f in enumerate(idx):
+                    k = (r + j) % self.N
+                    if held[k] != f:
+                        for slot, feat in zip(ring['slots'], (L1, L2, L3)):
+                            slot[k].copy_(feat[f])
+                        held[k] = f
+                ring['sx'].copy_(clip[t:t + 1])
+                graph, gout = self._ring_graph(ring, r)
                 graph.replay()
                 outs.append(gout.clone())
             else:
