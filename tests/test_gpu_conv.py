@@ -8,7 +8,7 @@ from gpu_util import check, dev, gemm_modes
 
 pytestmark = pytest.mark.gpu
 # exact-f32 MFMA: an fmaf chain -> tight; bf16x3 split: ~2^-17 per product
-TOLS = {'f32': 2e-5, 'bf16x3': 1e-4}
+TOLS = {'f32': 2e-5, 'bf16x3': 1e-4, 'bf16x2': 2e-2, 'bf16': 2e-2}   # (speed modes: tests/test_gpu_modes.py)
 
 CASES = [
     # C1, C2, Co, k, stride, act, residual, pixel_shuffle, B, H, W
@@ -77,7 +77,7 @@ def test_conv_block_forward_backward(case, gemm_mode):
         with torch.no_grad():
             z = _ref(x1.double(), None if x2 is None else x2.double(), conv.weight.double(), conv.bias.double(), None,
                      stride, 'none', ps)
-            gout = gout * (z.abs() > 1e-3).float()
+            gout = gout * (z.abs() > (1e-3 if gemm_mode in ('f32', 'bf16x3') else 5e-2)).float()   # (speed modes perturb z by ~2e-3 |z|)
 
     # float64 CPU reference
     r = [t.double().requires_grad_(True) if t is not None else None for t in (x1, x2, res)]

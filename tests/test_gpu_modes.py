@@ -221,3 +221,18 @@ def test_training_steps_in_the_speed_modes_track_the_default_mode(speed_mode):
     rel = float((u_got - u_ref).norm() / u_ref.norm())
     print('parameter update after 3 steps: rel l2 difference %.3f' % rel)
     assert rel <= 0.2 and torch.isfinite(u_got).all()   # (measured: 0.09)
+
+
+def _speed_mode_conv_cases():
+    from test_gpu_conv import CASES, _random_cases
+    # the 3 x 3 stride-1 layers with more than 32 output channels: the 64-row m-block kernels the modes act in (ragged tiles, concat
+    # inputs, residuals, PixelShuffle stores, widths on and off the vector path)
+    return [c for c in CASES + _random_cases(36, 20260928) if c[3] == 3 and c[4] == 1 and c[2] > 32]
+
+
+@pytest.mark.parametrize('case', _speed_mode_conv_cases(), ids=lambda c: '-'.join(str(v) for v in c))
+def test_conv_shapes_in_the_speed_modes(case, speed_mode):
+    """The shape sweep of tests/test_gpu_conv.py (forward, data / concat / residual / weight / bias gradients against f64) in the speed modes,
+    at their tolerance: the reduced-term instantiations share every addressing path with the default kernels."""
+    from test_gpu_conv import test_conv_block_forward_backward
+    test_conv_block_forward_backward(case, speed_mode)
