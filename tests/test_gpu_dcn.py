@@ -36,7 +36,7 @@ def _compare(args, gout, tol=TOL):
     check('out', out, oref, tol)
     for name, a, r in zip(('grad_input', 'grad_offset', 'grad_mask', 'grad_weight', 'grad_bias'), grads, gref):
         if r is not None:
-            check(name, a, r, TOL_G)
+            check(name, a, r, max(TOL_G, tol))   # (the speed modes pass their own tolerance)
 
 
 def test_fixture_dcn_op(gemm_mode):
@@ -79,7 +79,7 @@ def test_random_shapes_vs_oracle(shape, gemm_mode):
     w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
     b = torch.randn(Co, generator=g) if with_bias else None
     gout = torch.randn(B, Co, Ho, Wo, generator=g)
-    _compare((x, off, m, w, b, stride, pad, dil, dg), gout, 2e-5 if gemm_mode == 'f32' else 1e-4)
+    _compare((x, off, m, w, b, stride, pad, dil, dg), gout, {'f32': 2e-5, 'bf16x3': 1e-4}.get(gemm_mode, 2e-2))   # (speed modes: test_gpu_modes.py)
 
 
 def _random_shapes(n, seed):

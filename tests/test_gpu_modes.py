@@ -236,3 +236,17 @@ def test_conv_shapes_in_the_speed_modes(case, speed_mode):
     at their tolerance: the reduced-term instantiations share every addressing path with the default kernels."""
     from test_gpu_conv import test_conv_block_forward_backward
     test_conv_block_forward_backward(case, speed_mode)
+
+
+def _speed_mode_dcn_cases():
+    from test_gpu_dcn import SHAPES, _random_shapes
+    # more than 32 output channels, stride / dilation 1: dcn_fwd3<MT >= 2>, dcn_bwdin5<NK >= 4>, dcn_bwdw4 -- the kernels the modes act in
+    return [c for c in SHAPES + _random_shapes(14, 928) if c[2] > 32 and c[6] == 1 and c[8] == 1]
+
+
+@pytest.mark.parametrize('shape', _speed_mode_dcn_cases(), ids=lambda s: '-'.join(str(v) for v in s))
+def test_dcn_shapes_in_the_speed_modes(shape, speed_mode):
+    """The DCN operator's shape sweep (tests/test_gpu_dcn.py: ragged tiles, group counts, every offset regime of the backward's window
+    selection) in the speed modes, against the oracle at their tolerance."""
+    from test_gpu_dcn import test_random_shapes_vs_oracle
+    test_random_shapes_vs_oracle(shape, speed_mode)
