@@ -131,3 +131,21 @@ def test_packs_with_other_geometries_vs_reference_wiring():
     ref1 = O.deform_conv(x, off, p1.weight.detach(), (2, 1), (1, 0), 1, 2, 2)
     got1 = p1.to(dev())(x.to(dev()))
     assert l2_err(got1, ref1) <= 2e-5, l2_err(got1, ref1)
+
+
+def test_generic_path_errors_are_loud():
+    from realvsr_amd import functional as RF
+    d = dev()
+    x = torch.randn(1, 4, 6, 6, device=d, dtype=torch.float64)
+    w = torch.randn(4, 4, 5, 5, device=d, dtype=torch.float64)
+    with pytest.raises(TypeError):      # mixed element types
+        RF.modulated_deform_conv(x, torch.zeros(1, 50, 6, 6, device=d), torch.ones(1, 25, 6, 6, device=d, dtype=torch.float64), w, None, 1, 2, 1, 1, 1)
+    with pytest.raises(ValueError):     # a kernel larger than the padded input
+        RF.modulated_deform_conv(x, torch.zeros(1, 50, 1, 1, device=d, dtype=torch.float64), torch.ones(1, 25, 1, 1, device=d, dtype=torch.float64),
+                                 torch.randn(4, 4, 9, 9, device=d, dtype=torch.float64), None, 1, 0, 1, 1, 1)
+    with pytest.raises(RuntimeError):   # channels not divisible into the groups
+        RF.modulated_deform_conv(x, torch.zeros(1, 50, 6, 6, device=d, dtype=torch.float64), torch.ones(1, 25, 6, 6, device=d, dtype=torch.float64),
+                                 torch.randn(3, 2, 5, 5, device=d, dtype=torch.float64), None, 1, 2, 1, 3, 1)
+    with pytest.raises(TypeError):      # an element type the operator does not take
+        RF.modulated_deform_conv(x.to(torch.bfloat16), torch.zeros(1, 50, 6, 6, device=d, dtype=torch.bfloat16),
+                                 torch.ones(1, 25, 6, 6, device=d, dtype=torch.bfloat16), w.to(torch.bfloat16), None, 1, 2, 1, 1, 1)
