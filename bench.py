@@ -58,13 +58,14 @@ PMC_PROFILE = {64: 'profiles/r04_dcn_fwd_pmc.json', 128: 'profiles/r03_dcn_fwd_p
 
 
 def model_opt(args, world):
+    force = bool(getattr(args, 'force_allreduce', False))
     net = dict(which_model_G='EDVR', nf=args.nf, nc=3, nframes=args.nframes, groups=8, front_RBs=5,
                back_RBs=args.back_rbs, center=None, predeblur=False, HR_in=False, w_TSA=True)
-    return {'model': 'VideoSR_AllPair_YCbCr_Split', 'dist': world > 1, 'gpu_ids': [0], 'is_train': True, 'scale': 4,
+    return {'model': 'VideoSR_AllPair_YCbCr_Split', 'dist': world > 1 or force, 'gpu_ids': [0], 'is_train': True, 'scale': 4,
             'augment': None, 'network_G': net, 'path': {'pretrain_model_G': None, 'strict_load': True},
             'train': {'pixel_criterion_y': 'lappyr', 'pixel_weight_y': 1.0, 'pixel_criterion_c': 'gw',
                       'pixel_weight_c': 1.0, 'weight_decay_G': 0, 'ft_tsa_only': 0, 'lr_G': 1e-4, 'beta1': 0.9,
-                      'beta2': 0.99}}
+                      'beta2': 0.99, 'force_allreduce': force}}
 
 
 def init_weights(net, offset_init_std=0.01):
@@ -123,7 +124,7 @@ class DcnTimer:
     """HIP events around every fused-DCN forward (and backward) launch on the launching (current) stream."""
 
     def __init__(self):
-        self.events, self.bytes, self.bwd_events, self.lds_bytes = [], 0.0, [], 0.0
+        self.events, self.bytes, self.bwd_events, self.lds_bytes, self.flops = [], 0.0, [], 0.0, 0.0
 
     def install(self):
         from realvsr_amd import functional as RF
@@ -142,6 +143,7 @@ class DcnTimer:
             Wo = (W + 2 * pad - (2 * dil + 1)) // stride + 1
             timer.events.append((s, e))
             timer.bytes += 4.0 * (C * H * W + (216 + Co) * Ho * Wo) * B + 4.0 * Co * C * 9
+            timer.flops += 2.0 * C * 9 * Co * Ho * Wo * B     # the GEMM of the fused DCN, f32-equivalent
             # LDS bytes the kernel's formulation reads per output pixel: 9 taps x 4 corners x C channels x 4 B of x tile (the gather) +
             # the weight fragments a wave re-reads per (tap, 16-channel chunk): 4 x 1 KB (hi, lo of two 32-row blocks; x2 for Co = 128) per 32 pixels
             timer.lds_bytes += (9 * 4 * C * 4 + 9 * (C // 16) * 4096 * max(1, Co // 64) / 32.0) * Ho * Wo * B
@@ -167,6 +169,44 @@ class DcnTimer:
 
     def backward_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.bwd_events)
+
+    def matrix_frac(self, gemm_mode):
+        """The same launches against the matrix-core roof: MFMA work issued (GEMM_PASSES bf16 products per f32 product) / time / dense peak."""
+        ms = sum(s.elapsed_time(e) for s, e in self.events)
+        if ms <= 0:
+            return None
+        peak = MFMA_F32_PEAK_TFLOPS if gemm_mode == 'f32' else MFMA_BF16_PEAK_TFLOPS
+        return GEMM_PASSES[gemm_mode] * self.flops / (ms * 1e-3) / 1e12 / peak
+
+
+def dcn_roofline(kernel, C, Co, gemm_mode, timer):
+    """The `roofline` object of the fused DCN forward from a DcnTimer: against HBM where the issued matrix work per byte is below the ridge
+    (nf64), against the matrix cores where it is above (nf128 in the 3-term format, VERDICT r4 #3); the other fraction rides beside it."""
+    nl, kms, kbytes = timer.result()
+    bound, ai = dcn_bound(C, Co, gemm_mode)
+    hbm = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else None
+    mfrac = timer.matrix_frac(gemm_mode)
+    peak_tf = MFMA_F32_PEAK_TFLOPS if gemm_mode == 'f32' else MFMA_BF16_PEAK_TFLOPS
+    r = {'kernel': kernel, 'bound': bound}
+    if bound == 'mfma':
+        r.update({'achieved': None if mfrac is None else round(mfrac * peak_tf, 1), 'peak': peak_tf, 'unit': 'TFLOP/s',
+                  'frac': None if mfrac is None else round(mfrac, 4),
+                  'hbm_frac': None if hbm is None else round(hbm / HBM_PEAK_GBS, 4), 'hbm_achieved_GBs': None if hbm is None else round(hbm, 2)})
+    else:
+        r.update({'achieved': None if hbm is None else round(hbm, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                  'frac': None if hbm is None else round(hbm / HBM_PEAK_GBS, 4),
+                  'matrix_frac': None if mfrac is None else round(mfrac, 4)})
+    r.update({'issued_flop_per_byte': round(ai, 1), 'ridge_flop_per_byte': round(peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+              'launches': nl, 'avg_launch_ms': round(kms / max(nl, 1), 4), 'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1))})
+    return r
+
+
+def dcn_bound(C, Co, gemm_mode):
+    """Which roof the fused DCN forward sits under (SURVEY.md 8d): arithmetic intensity of the issued matrix work, passes * 2 C 9 Co FLOP over
+    4 (C + 216 + Co) B per output pixel, against the ridge peak_flops / 8 TB/s.  nf64 in the 3-term format: 161 < 312 -> HBM; nf128: 469 -> MFMA."""
+    peak = MFMA_F32_PEAK_TFLOPS if gemm_mode == 'f32' else MFMA_BF16_PEAK_TFLOPS
+    ai = GEMM_PASSES[gemm_mode] * 2.0 * C * 9 * Co / (4.0 * (C + 216 + Co))
+    return ('mfma' if ai > peak * 1e12 / (HBM_PEAK_GBS * 1e9) else 'hbm'), ai
 
 
 class _Proxy:
@@ -256,6 +296,8 @@ def timed_steps(model, n, first_step):
     timer.uninstall()
     nl, kms, kbytes = timer.result()
     frac = kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None
+    from realvsr_amd import _lib as rlib
+    timed_steps.last_matrix_frac = timer.matrix_frac(rlib.get_gemm_mode())
     return 1e3 * dt / n, frac, timer.backward_ms() / n
 
 
@@ -383,9 +425,14 @@ def parity_check(model, ora):
     dev = model.device
     keep_L, keep_H = getattr(model, 'var_L', None), getattr(model, 'var_H', None)
     model.feed_data({'LQs': ora['x'].to(dev), 'GT': ora['gt'].to(dev)})
-    model.optimizer_G.zero_grad()
+    if model.reducer is not None:
+        model.reducer.zero_grad()
+    else:
+        model.optimizer_G.zero_grad()
     total, _ = model.forward_loss()
     total.backward()
+    if model.reducer is not None:
+        model.reducer.finish()
     torch.cuda.synchronize()
 
     def l2(a, b):
@@ -441,7 +488,7 @@ def extra_train_line(base, nf, nframes, batch, steps=3):
     same harness, same offset protocol, 3 untimed + `steps` timed steps."""
     from realvsr_amd import loss as L
     from realvsr_amd.VideoSR_model import create_model
-    a = _Cfg(**dict(vars(base), nf=nf, nframes=nframes, batch=batch))
+    a = _Cfg(**dict(vars(base), nf=nf, nframes=nframes, batch=batch, force_allreduce=False))
     dev = torch.device('cuda', torch.cuda.current_device())
     torch.manual_seed(0)
     model = create_model(model_opt(a, 1))
@@ -453,6 +500,7 @@ def extra_train_line(base, nf, nframes, batch, steps=3):
         offset_stats(model.netG, x, a.offset_px)
     model.feed_data({'LQs': x, 'GT': gt})
     ms, frac, bwd = timed_steps(model, steps, 1)
+    mfrac = timed_steps.last_matrix_frac
     st = offset_stats(model.netG, x)
     l1 = st.get('pcd_align.L1_dcnpack', (None, None))
     from realvsr_amd import _lib as rlib
@@ -460,6 +508,8 @@ def extra_train_line(base, nf, nframes, batch, steps=3):
     out = {'workload': 'EDVR nf%d, %d-frame %dx%d LR windows, batch %d, fwd + loss + bwd + Adam step' % (nf, nframes, a.height, a.width, batch),
            'ms_per_step': round(ms, 2), 'value': round(batch / (ms * 1e-3), 3), 'unit': 'HR frames/s', 'steps': steps,
            'dcn_fwd_frac': None if frac is None else round(frac, 4), 'dcn_bwd_ms_per_step': round(bwd, 2),
+           'dcn_fwd_bound': dcn_bound(nf, nf, rlib.get_gemm_mode())[0],
+           'dcn_fwd_matrix_frac': None if mfrac is None else round(mfrac, 4),
            'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3), 'conv_frac_of_bf16_peak': conv['frac'],
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     if rlib.get_gemm_mode() == 'bf16x3':   # the opt-in speed mode on the same workload (2 untimed + 2 timed steps)
@@ -501,6 +551,8 @@ def infer_line(a, T=10, offset_px=None):
     torch.cuda.synchronize()
     timer.uninstall()
     nl, kms, kbytes = timer.result()
+    from realvsr_amd import _lib as rlib
+    mfrac = timer.matrix_frac(rlib.get_gemm_mode())
     run_g = SlidingWindowRunner(net, a.nframes, padding='replicate', chunk=2, use_graph=True)
     out_g, ms_graph = timed(run_g)
     res = {'workload': 'EDVR nf%d, %d-frame windows over a %d-frame %dx%d clip -> %dx%d, forward only, per-frame feature reuse'
@@ -509,11 +561,12 @@ def infer_line(a, T=10, offset_px=None):
            'ms_per_frame_hipgraph': round(ms_graph, 2), 'value': round(1e3 / min(ms_eager, ms_graph), 3), 'unit': 'HR frames/s',
            'graph_bit_identical': bool(torch.equal(out, out_g)),
            'dcn_fwd_frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
+           'dcn_fwd_bound': dcn_bound(a.nf, a.nf, rlib.get_gemm_mode())[0],
+           'dcn_fwd_matrix_frac': None if mfrac is None else round(mfrac, 4),
            'dcn_fwd_avg_launch_ms': round(kms / max(nl, 1), 4), 'offset_abs_mean_px': None if l1[0] is None else round(l1[0], 3),
            'note': 'hipGraph path: a ring of N feature slots (one slot overwritten per frame) + one captured graph per rotation of the ring, '
                    'replayed round-robin; the eager pass is GPU-bound at this frame size (no launch gaps), so the replay has nothing to recover',
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
-    from realvsr_amd import _lib as rlib
     if rlib.get_gemm_mode() == 'bf16x3':   # the opt-in speed mode on the same clip (eager)
         rlib.set_gemm_mode('bf16')
         try:
@@ -561,6 +614,10 @@ def main():
     ap.add_argument('--dry-run', action='store_true', help='N > 1: check launcher env, device count and backend, then exit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true', help='skip the post-run offset sweep and the f32-mode step')
+    ap.add_argument('--force-allreduce', action='store_true',
+                    help='N = 1: initialise a one-rank RCCL process group and run the bucketed gradient all-reduce (hooks, one async '
+                         'all_reduce per bucket, finish) inside every step -- arithmetically the identity, but it loads librccl and '
+                         'exercises the overlap path on a 1-GPU box; the line then carries the `allreduce` object')
     pre, _ = ap.parse_known_args()
     if pre.config == 3:
         ap.set_defaults(nf=128, nframes=7, batch=16)
@@ -596,7 +653,8 @@ def main():
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    use_pg = world > 1 or args.force_allreduce
+    if use_pg:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -625,11 +683,17 @@ def main():
                               'dtype': dtype_of(gemm_mode), 'data': 'synthetic',
                               'config': {'workload': res['workload'], 'parallelism': 'replicas x%d' % world, 'gemm': gemm_mode,
                                          'offset_abs_mean_px': res['offset_abs_mean_px']},
-                              'roofline': {'kernel': 'fused DCN forward', 'bound': 'hbm', 'frac': res['dcn_fwd_frac'], 'peak': HBM_PEAK_GBS,
-                                           'unit': 'GB/s', 'achieved': None if res['dcn_fwd_frac'] is None else round(res['dcn_fwd_frac'] * HBM_PEAK_GBS, 1),
-                                           'avg_launch_ms': res['dcn_fwd_avg_launch_ms'], 'traffic': None},
+                              'roofline': ({'kernel': 'fused DCN forward', 'bound': 'mfma', 'frac': res['dcn_fwd_matrix_frac'],
+                                            'peak': MFMA_BF16_PEAK_TFLOPS if gemm_mode != 'f32' else MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                            'achieved': None if res['dcn_fwd_matrix_frac'] is None else round(
+                                                res['dcn_fwd_matrix_frac'] * (MFMA_BF16_PEAK_TFLOPS if gemm_mode != 'f32' else MFMA_F32_PEAK_TFLOPS), 1),
+                                            'hbm_frac': res['dcn_fwd_frac'], 'avg_launch_ms': res['dcn_fwd_avg_launch_ms'], 'traffic': None}
+                                           if res['dcn_fwd_bound'] == 'mfma' else
+                                           {'kernel': 'fused DCN forward', 'bound': 'hbm', 'frac': res['dcn_fwd_frac'], 'peak': HBM_PEAK_GBS,
+                                            'unit': 'GB/s', 'achieved': None if res['dcn_fwd_frac'] is None else round(res['dcn_fwd_frac'] * HBM_PEAK_GBS, 1),
+                                            'matrix_frac': res['dcn_fwd_matrix_frac'], 'avg_launch_ms': res['dcn_fwd_avg_launch_ms'], 'traffic': None}),
                               'detail': res}), flush=True)
-        if world > 1:
+        if use_pg:
             torch.distributed.destroy_process_group()
         return
     torch.manual_seed(0 if rank == 0 else 12345 + rank)   # ranks > 0 start from DIFFERENT weights on purpose:
@@ -677,7 +741,7 @@ def main():
     timer.uninstall()
     loss = model.loss_terms['l_pix']
     allreduce = None
-    if world > 1:
+    if use_pg:
         # every rank must hold bit-identical parameters after the last step (same averaged gradients, same Adam arithmetic)
         probe = model.optimizer_G.buffers.param.double().sum()
         lo, hi = probe.clone(), probe.clone()
@@ -687,7 +751,8 @@ def main():
         r = model.reducer
         allreduce = {'buckets': len(r.buckets), 'bytes': 4 * r.buffers.numel, 'bucket_bytes': [4 * (e - s) for s, e in r.buckets],
                      'issued_during_backward': r.stats_issued_in_backward, 'exposed_ms': round(r.exposed_ms(), 3),
-                     'backend': backend, 'params_identical_after_last_step': True,
+                     'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world': world,
+                     'params_identical_after_last_step': True,
                      'note': 'exposed_ms = stream time between entering finish() and the last bucket being ready, per step, '
                              'rank 0, averaged over the timed steps; issued_during_backward = buckets whose all-reduce was '
                              'enqueued from a gradient hook, i.e. before backward returned (last step)'}
@@ -737,14 +802,9 @@ def main():
                        'offset_abs_mean_px_per_dcn': {k.split('.')[-1]: round(v[0], 4) for k, v in off.items()},
                        'offset_px_requested': args.offset_px,
                        'loss_last_step': round(float(loss.item()), 6)},
-            'roofline': {'kernel': 'dcn_fwd3_kernel (+ its weight pre-pack), fused DCN forward', 'bound': 'hbm',
-                         'achieved': round(kbytes / (kms * 1e-3) / 1e9, 2) if kms > 0 else None,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else None,
-                         'traffic': traffic, 'traffic_source': traffic_source, 'launches': nl,
-                         'avg_launch_ms': round(kms / max(nl, 1), 4),
-                         'algorithmic_bytes_per_launch': round(kbytes / max(nl, 1)),
-                         'dcn_bwd_ms_per_step': round(timer.backward_ms() / max(args.steps, 1), 3)},
+            'roofline': dict(dcn_roofline('dcn_fwd3_kernel (+ its weight pre-pack), fused DCN forward', args.nf, args.nf, gemm_mode, timer),
+                             traffic=traffic, traffic_source=traffic_source,
+                             dcn_bwd_ms_per_step=round(timer.backward_ms() / max(args.steps, 1), 3)),
         }
         if kms > 0:
             # what the fused DCN forward is actually bound by (profiles/r04_notes.md): not HBM -- its traffic is 1.12x the algorithmic bytes --
@@ -805,7 +865,7 @@ def main():
                 extra['config5'] = {'error': repr(e)[:300]}
             line['extra'] = extra
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 

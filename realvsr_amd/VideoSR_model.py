@@ -95,7 +95,8 @@ class VideoSRModel:
         self.optimizers.append(self.optimizer_G)
         if self.dist:
             self.reducer = BucketedGradAllReduce(None, bucket_mb=float(os.environ.get('RVSR_BUCKET_MB', train_opt.get('bucket_mb', 4.0))),
-                                                 buffers=self.optimizer_G.buffers, broadcast=False)
+                                                 buffers=self.optimizer_G.buffers, broadcast=False,
+                                                 force=bool(train_opt.get('force_allreduce')))
         self.log_dict = OrderedDict()
 
     # ------------------------------------------------------------------ data

@@ -134,18 +134,23 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
             x, feat = x[0], x[1]
         else:
             feat = x
-        fused = (self.kernel_size == (3, 3) and self.groups == 1 and
-                 self.padding == self.dilation * (self.kernel_size[0] // 2))
+        # The fused kernels cover what the functional operator's fused path covers (RF._dcn_fused_ok: f32, 3 x 3, isotropic geometry, one
+        # group, channels per deformable group a multiple or a divisor of 8) with the offset conv on the fused conv kernel (padding 1,
+        # stride 1 / 2); everything else falls through to the reference's wiring on the operator
+        st, pd, dl = RF._pair2(self.stride), RF._pair2(self.padding), RF._pair2(self.dilation)
+        fused = (self.kernel_size == (3, 3) and pd == (1, 1) and dl == (1, 1) and st[0] in (1, 2) and feat.dtype == torch.float32 and
+                 RF._dcn_fused_ok(x, self.weight, st, pd, dl, self.groups, self.deformable_groups))
         if fused:
             om = RF.conv2d(feat, self.conv_offset_mask, x_premask=feat_premask)
-            return RF.dcn_pack(x, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                               self.deformable_groups, act, slope, sink)
+            return RF.dcn_pack(x, om, self.weight, self.bias, st[0], pd[0], dl[0], self.deformable_groups, act, slope, sink)
         if feat_premask is not None:
             # the producer of `feat` ran with grad_premasked=True and relies on THIS conv to apply its activation derivative:
             # only the fused branch does
             raise RuntimeError('ModulatedDeformConvPack: feat_premask needs the fused 3x3 / groups=1 path')
-        if self.kernel_size == (3, 3) and self.padding == 1 and self.dilation == 1 and act == RF.ACT_NONE and sink is None:
-            # groups > 1 (deform_conv.py:284-292 as written): the unfused wiring on the composed operator
+        if (self.kernel_size == (3, 3) and pd == (1, 1) and dl == (1, 1) and st[0] == st[1] and st[0] in (1, 2) and
+                feat.dtype == torch.float32 and act == RF.ACT_NONE and sink is None):
+            # groups > 1, or channels per deformable group the fused kernels do not tile (deform_conv.py:284-292 as written): the unfused
+            # wiring on the composed operator, offset conv on the fused conv kernel
             out = RF.conv2d(feat, self.conv_offset_mask)
             o1, o2, mask = torch.chunk(out, 3, dim=1)
             return modulated_deform_conv(x, torch.cat((o1, o2), dim=1), torch.sigmoid(mask), self.weight, self.bias, self.stride,

@@ -41,10 +41,14 @@ def broadcast_parameters(module_or_tensors, src=0, process_group=None):
 
 
 class BucketedGradAllReduce:
-    def __init__(self, params, bucket_mb=4.0, process_group=None, buffers=None, broadcast=True):
-        """params: iterable of parameters (ignored when `buffers`, a FlatBuffers that already holds them, is given)."""
+    def __init__(self, params, bucket_mb=4.0, process_group=None, buffers=None, broadcast=True, force=False):
+        """params: iterable of parameters (ignored when `buffers`, a FlatBuffers that already holds them, is given).
+        force: run the whole reducer path -- gradient hooks, one asynchronous all_reduce per bucket, finish() -- even in a
+        one-rank group, where it is arithmetically the identity (sum over one rank, times 1/1).  That is how a 1-GPU box
+        exercises RCCL itself (tests/test_gpu_dist.py, `bench.py --force-allreduce`); needs an initialised process group."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.buffers = buffers if buffers is not None else FlatBuffers([list(params)])
         self.params = list(self.buffers.order)
         self.flat = self.buffers.grad
@@ -71,7 +75,7 @@ class BucketedGradAllReduce:
         self._next = 0          # next bucket to issue (strictly ascending on every rank)
         self._works = []
         self.reset_stats()
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
@@ -106,7 +110,7 @@ class BucketedGradAllReduce:
 
     def finish(self):
         """Wait for the in-flight buckets and turn the sums into means. Call before optimizer.step()."""
-        if self.world == 1:
+        if not self.active:
             return
         self.stats_issued_in_backward = self._next
         ev = None

@@ -188,6 +188,9 @@ class FlatAdam(torch.optim.Optimizer):
             self.buffers.param[s:e].copy_(pv)
             self.exp_avg[s:e].copy_(m1)
             self.exp_avg_sq[s:e].copy_(m2)
+        # the skip set belongs to THIS step's gradients: the next step decides again (a finish() that runs before it may pre-decide; gradients
+        # cleared by nn.Module.zero_grad() / p.grad = None, or two steps without a zero_grad, must not reuse a stale list -- ADVICE r4)
+        self.buffers.no_grad = None
         # the kernels above changed every parameter through raw pointers: re-pack all cached bf16 hi/lo weight images, one launch
         RF.packed_weights.repack()
         RF.dcn_offset_stats.advance()   # (the DCN forwards' halo choice lags by optimizer steps, functional.DcnOffsetStats)

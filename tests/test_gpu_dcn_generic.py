@@ -133,6 +133,45 @@ def test_packs_with_other_geometries_vs_reference_wiring():
     assert l2_err(got1, ref1) <= 2e-5, l2_err(got1, ref1)
 
 
+@pytest.mark.parametrize('what', ['tuple_geometry', 'aniso_stride', 'f64', 'cpg12'])
+def test_3x3_packs_outside_the_fused_kernels_fall_through(what):
+    """a 3 x 3 / groups = 1 pack used to take the fused branch whatever else it was given.  Tuple stride / padding / dilation, an
+    anisotropic stride, f64 tensors and 12 channels per deformable group must reach the reference's wiring on the operator (general path)
+    -- and isotropic tuples must still reach the fused kernels; forward and input gradient against torch's conv2d + the CPU oracle."""
+    from oracle import dcn_oracle as O
+    from realvsr_amd.archs.dcn import ModulatedDeformConvPack
+    C, Co, dg, stride, dtype, tol = 16, 8, 2, 1, torch.float32, 2e-5
+    if what == 'tuple_geometry':
+        stride = (1, 1)
+    elif what == 'aniso_stride':
+        stride = (1, 2)
+    elif what == 'f64':
+        dtype, tol = torch.float64, 1e-11
+    elif what == 'cpg12':
+        C, dg = 24, 2
+    padding, dilation = ((1, 1), (1, 1)) if isinstance(stride, tuple) else (1, 1)
+    torch.manual_seed(12)
+    pack = ModulatedDeformConvPack(C, Co, 3, stride=stride, padding=padding, dilation=dilation, groups=1, deformable_groups=dg, bias=True)
+    with torch.no_grad():
+        pack.conv_offset_mask.weight.normal_(0, 0.05)
+        pack.conv_offset_mask.bias.normal_(0, 0.3)
+    pack = pack.to(dtype)
+    x = torch.randn(2, C, 12, 16, dtype=dtype)
+    xr = x.clone().requires_grad_(True)
+    om = F.conv2d(xr, pack.conv_offset_mask.weight.detach(), pack.conv_offset_mask.bias.detach(), stride=stride, padding=1)
+    o1, o2, mk = torch.chunk(om, 3, dim=1)
+    ref = O.modulated_deform_conv(xr, torch.cat((o1, o2), 1), torch.sigmoid(mk), pack.weight.detach(), pack.bias.detach(), stride, padding, dilation, 1, dg)
+    gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5), dtype=dtype)
+    ref.backward(gout)
+    xd = x.to(dev()).requires_grad_(True)
+    got = pack.to(dev())(xd)
+    got.backward(gout.to(dev()))
+    assert got.dtype == dtype
+    e_o, e_g = l2_err(got, ref), l2_err(xd.grad, xr.grad)
+    print('%s: out %.2e grad_input %.2e' % (what, e_o, e_g))
+    assert e_o <= tol and e_g <= 5 * tol, (what, e_o, e_g)
+
+
 def test_generic_path_errors_are_loud():
     from realvsr_amd import functional as RF
     d = dev()

@@ -1,5 +1,5 @@
-"""The N > 1 path on real kernels: two ranks sharing ONE MI355X over gloo (the driver has no multi-GPU box for tests;
-RCCL itself is exercised by the driver's scaling run).  -m gpu
+"""The N > 1 path on real kernels: two ranks sharing ONE MI355X over gloo (the driver has no multi-GPU box for tests), and RCCL
+itself in a one-rank group with the reducer's hook path forced on (`BucketedGradAllReduce(force=True)`).  -m gpu
 
   * the real EDVR training step through VideoSRModel(dist) -> FlatAdam buffers -> BucketedGradAllReduce hooks on the
     custom autograd Functions: averaged gradients == full-batch gradients, ranks end with identical parameters
@@ -108,6 +108,92 @@ def test_two_ranks_one_gpu_match_full_batch():
     perr = ((got[0][1].double() - ref_p.double()).norm() / ref_p.double().norm()).item()
     print('parameters after 2 steps, 2 ranks vs 1: rel l2 err %.3e' % perr)
     assert perr <= 1e-4, perr
+
+
+_RCCL_WORLD1 = r"""
+import json, os, sys
+sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, 'tests')); sys.path.insert(0, os.path.join(%(repo)r, 'tests', 'golden'))
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%(port)r)
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))   # nccl IS RCCL on ROCm
+from weights import fill_state_dict
+from realvsr_amd.VideoSR_model import create_model
+net = dict(which_model_G='EDVR', nf=64, nc=3, nframes=5, groups=8, front_RBs=2, back_RBs=3, center=None, predeblur=False, HR_in=False, w_TSA=True)
+def opt(dist_on):
+    return {'model': 'VideoSR_AllPair_YCbCr_Split', 'dist': dist_on, 'gpu_ids': [0], 'is_train': True, 'scale': 4, 'augment': None,
+            'network_G': net, 'path': {'pretrain_model_G': None, 'strict_load': True},
+            'train': {'pixel_criterion_y': 'lappyr', 'pixel_weight_y': 1.0, 'pixel_criterion_c': 'gw', 'pixel_weight_c': 0.5, 'weight_decay_G': 0,
+                      'ft_tsa_only': 0, 'lr_G': 1e-3, 'beta1': 0.9, 'beta2': 0.99, 'bucket_mb': 0.5, 'force_allreduce': dist_on}}
+g = torch.Generator().manual_seed(11)
+x, gt = torch.rand(2, 5, 3, 48, 64, generator=g), torch.rand(2, 3, 192, 256, generator=g)
+res = {}
+for tag, on in (('plain', False), ('plain2', False), ('rccl', True)):
+    torch.manual_seed(3)
+    m = create_model(opt(on))
+    fill_state_dict(m.netG, 808, offset_std=0.02)
+    m.feed_data({'LQs': x, 'GT': gt})
+    for step in (1, 2):
+        m.optimize_parameters(step)
+    torch.cuda.synchronize()
+    res[tag] = m.optimizer_G.buffers.param.detach().cpu().clone()
+    if on:
+        r = m.reducer
+        info = {'active': r.active, 'world': r.world, 'buckets': len(r.buckets), 'issued_during_backward': r.stats_issued_in_backward,
+                'exposed_ms': r.exposed_ms(), 'backend': dist.get_backend()}
+    else:
+        assert m.reducer is None
+info['identical'] = bool(torch.equal(res['plain'], res['rccl']))
+# (the DCN input gradient is flushed with f32 global atomics where the halos of up to four workgroups overlap: two plain runs need not agree
+# in the last bit, so the all-reduce is held to "no further than a plain repeat")
+info['repeat_identical'] = bool(torch.equal(res['plain'], res['plain2']))
+info['diff_rccl'] = float((res['plain'].double() - res['rccl'].double()).abs().max())
+info['diff_repeat'] = float((res['plain'].double() - res['plain2'].double()).abs().max())
+info['rccl_loaded'] = any('librccl' in l for l in open('/proc/self/maps'))
+print('RESULT ' + json.dumps(info), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_one_rank_forced_allreduce_matches_plain_step():
+    """RCCL on hardware before a multi-GPU node exists (reference: codes/train.py:19-26 init_dist(backend='nccl')): a
+    one-rank `nccl` process group on cuda:0, a real EDVR (nf64, 5 frames, TSA) `optimize_parameters` with the reducer forced on -- gradient
+    hooks, one asynchronous all_reduce per bucket on RCCL's stream, finish() -- against the same two steps without a reducer: parameters
+    bit-identical (a one-rank sum times 1/1), at least one bucket issued from a hook while backward was still running, a finite exposed time,
+    and librccl mapped into the process."""
+    import math
+    code = _RCCL_WORLD1 % {'repo': REPO, 'port': str(_free_port())}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    info = json.loads([l for l in out.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
+    print(info)
+    assert info['backend'] == 'nccl' and info['active'] and info['world'] == 1 and info['rccl_loaded']
+    assert info['buckets'] > 3 and 1 <= info['issued_during_backward'] <= info['buckets']
+    assert math.isfinite(info['exposed_ms']) and info['exposed_ms'] >= 0.0
+    if info['repeat_identical']:
+        assert info['identical'], 'the forced one-rank all-reduce changed the parameters'
+    else:   # atomics made the plain step itself non-reproducible on this run: the all-reduce may not add to that
+        assert info['diff_rccl'] <= 4 * info['diff_repeat'] + 1e-12, info
+
+
+def test_bench_force_allreduce_line():
+    """`bench.py --gpus 1 --force-allreduce`: the driver's N = 1 line with the all-reduce inside every timed step, over RCCL."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'RVSR_BENCH_BACKEND'):
+        env.pop(k, None)
+    env['MASTER_PORT'] = str(_free_port())
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--force-allreduce', '--steps', '2', '--warmup', '1',
+                          '--batch', '1', '--height', '32', '--width', '48', '--no-cpu-baseline', '--no-extra', '--no-sweep'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    ar = rec['allreduce']
+    assert rec['n_gpus'] == 1 and ar['world'] == 1 and ar['backend'].startswith('nccl')
+    assert ar['buckets'] >= 1 and ar['bytes'] == sum(ar['bucket_bytes']) and ar['params_identical_after_last_step'] is True
+    assert 1 <= ar['issued_during_backward'] <= ar['buckets'] and ar['exposed_ms'] >= 0.0
 
 
 def test_bench_self_launches_n_ranks():
