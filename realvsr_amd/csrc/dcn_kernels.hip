@@ -437,6 +437,8 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     size_t b2 = rvsr_dcn_bwdin_auto_workspace_bytes(channels_out, channels);   // both weight images + the probe counter
     const size_t b5 = rvsr_dcn_bwdin5_workspace_bytes(channels_out, channels);
     if (b5 > b2) b2 = b5;
+    const size_t b6 = rvsr_dcn_bwd6_workspace_bytes(channels_out, channels);
+    if (b6 > b2) b2 = b6;
     return a > b2 ? a : b2;
 }
 
@@ -448,6 +450,15 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     TView g;
     g.p = gout; g.act = gact; g.slope = gact_slope; g.C = d.Co; g.Hs = g.Hv = d.Ho; g.Ws = g.Wv = d.Wo; g.mode = 0;
     const int nty = (d.Ho + 3) / 4;
+    if (gx && goff && gmask && gw && rvsr_g_gemm_mode != 1) {
+        // sixth generation: all five gradients from ONE sampling pass (dcn6_kernels.hip) where it covers the call
+        static const int gen6 = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();      // developer A/B switch
+        static const int halo6 = [] { const char* e = getenv("RVSR_DCN6_HALO"); return e ? atoi(e) : -1; }();
+        if (gen6 >= 7) {
+            const int rc6 = rvsr_launch_dcn_bwd6(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, gw, gb, workspace, workspace_bytes, st, halo6);
+            if (rc6 != RVSR_ERR_UNSUPPORTED) return rc6;
+        }
+    }
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
