@@ -1,66 +1,47 @@
-// dcn6_kernels.hip -- the WHOLE backward of the modulated DCN in one kernel, sixth generation (gfx950).
+// dcn6_kernels.hip -- backward of the modulated DCN, sixth generation (gfx950): dcn_bwdin6 (input / offset / mask gradient).
 //
-// Replaces, for the shape the EDVR-M training step runs (3 x 3, stride 1, dilation 1, 8 channels per deformable group, <= 64 output
-// channels), the pair dcn_bwdin5 (input / offset / mask gradient, dcn5_kernels.hip) + dcn_bwdw4 (weight / bias gradient,
-// dcn_bwdw4.inc), i.e. the reference's modulated_deform_conv_cuda_backward (deform_conv_cuda.cpp:571-685) with all of its kernels
-// (kernel.cu:636-767 col2im + col2im_coord, :571-633 the im2col recompute) and its three GEMMs (cpp:623-626, 659-671).
+// Replaces dcn_bwdin5 (dcn5_kernels.hip; the reference's modulated_deformable_col2im + col2im_coord pair, kernel.cu:636-767, with the
+// `columns = W^T gOut` GEMM of deform_conv_cuda.cpp:623-626 in front of them) where 8 divides the channels per deformable group.
 //
-// Why (profiles/r04_*): the pair cost 7.4 ms per L1 launch against 1.2 ms of forward -- 1.6 G vector wave-instructions against the
-// forward's 0.24 G.  Both kernels walked all 72 sampling geometries per pixel, both read x / offsets / masks / gOut, dcn_bwdin5 spent
-// half of its vector work on things the lane layout forced (two lane halves computing one geometry, partner-lane sums), and the weight
-// gradient rebuilt the column tile through 2-byte LDS stores.  Here:
-//   * ONE sampling pass.  bilinear(x) is formed once per (pixel, tap, channel); grad_mask, grad_offset, the grad_input scatter AND
-//     the column value col = mask * bilinear(x) of the weight gradient all come from it.
-//   * The M rows of col_grad = W^T gOut are PERMUTED in the packed weight image so that the accumulator registers of lane (pixel, half)
-//     hold all 8 channels of two taps (instead of 4 channels of four taps): a lane owns a whole (pixel, tap) -- one geometry per lane,
-//     no partner-lane sums, and the two halves of a wave work on different taps (5 lane iterations per chunk instead of 9 taps).
-//   * Packed f32 math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel broadcasts) on channel pairs.
-//   * The weight gradient gW[o, (c, tap)] = sum_px gOut[o, px] col[(c, tap), px] needs both operands with PIXELS along the MFMA's K
-//     (register) dimension, but the sampling pass produces pixels along the LANE dimension.  The transposition is done by the matrix
-//     core itself: an MFMA with a 0/1 selector as B operand, D = A x [I16 | 0] (+ A' x [0 | I16]), moves A[i = pixel][k = channel] to
-//     D[i = pixel][j = channel] whose register layout is (lane = j, register = i): exact (one non-zero product per output, f32
-//     accumulate), no LDS round trip, no 2-byte stores.  The same trick turns the gOut fragments (lane = pixel, K = output channel)
-//     into the A operand of the weight-gradient GEMM (lane = output channel, K = pixel).  The pixel order along K is whatever the D
-//     layout makes it -- the same for both operands, which is all a dot product needs.
-//   * CHUNK-MAJOR persistent schedule: a workgroup owns ONE 8-channel chunk (= one deformable group) and walks a contiguous range of
-//     8 x 32 pixel tiles, so the 64 x 80 weight-gradient block of its chunk stays in registers for the whole launch (96 accumulator
-//     registers per wave; deterministic partials at the end, reduced by rvsr_reduce_partials_kernel as before), the chunk's weight
-//     block is fetched once per workgroup, and the grad_offset / grad_mask planes of the group are written exactly once.  The
-//     workgroups of the nchunks chunks of one tile stream sit on the same XCD (linear workgroup id % 8), so the gOut tile they all
-//     read comes out of that XCD's L2.
-// The grad_input scatter is dcn_bwdin5's: one shared LDS window of 32-bit fixed-point cells, ds_add_u32 from every lane, scale from
-// Cauchy-Schwarz norms (no overflow for any input), flushed with one f32 global atomic per touched cell.
+// Why (profiles/r04_*, r05_notes.md): dcn_bwdin5 executed 1.06 G vector wave-instructions per L1 launch against the forward's 0.24 G --
+// 200 per (wave, tap) -- and half of them were forced by its lane layout: the accumulator registers of lane (pixel, half) held 4 channels
+// of FOUR taps, so both halves of a wave computed every sampling geometry, every tap needed three partner-lane sums
+// (v_permlane32_swap + nops) for grad_offset / grad_mask, and each lane carried four channels through scalar f32 arithmetic.  Here
+//   * the M rows of col_grad = W^T gOut are PERMUTED in the packed weight image so that lane (pixel, half) holds all 8 channels of TWO
+//     taps: a lane owns a whole (pixel, tap) -- one geometry per lane, no partner-lane sums, every lane stores its own grad_offset /
+//     grad_mask -- and the halves of a wave work on different taps: 5 lane iterations per chunk instead of 9 taps;
+//   * the per-channel arithmetic runs on channel PAIRS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel broadcasts);
+//   * the main path of a lane iteration is branch-free (dead lanes add 0 to spread cells and store beyond the buffer view); samples
+//     beyond the window take a rolled loop over the channels (global gather / atomics with the reference's rule set).
+// Everything else is dcn_bwdin5's: one shared LDS window of 32-bit fixed-point cells, ds_add_u32 from every lane, scale from
+// Cauchy-Schwarz norms (no overflow for any input), flushed with one f32 global atomic per touched cell; halo selected on the device.
+//
+// (A fully fused backward -- this kernel plus the weight gradient from the same sampling pass, column values transposed by the matrix
+// core -- is numerically right and kept as experiments/dcn_bwd6_fused.hip; it needs ~400 live registers per wave and ran 16 ms per L1
+// launch against 7.3 for the pair: profiles/r05_notes.md.)
 #include "dcn_tile.h"
 
-struct DcnBwd6Params {
-    DcnGeom d;
-    TView g;            // grad_output view (Co, Ho, Wo), plain, optional fused act'
-    float* gx;          // (B, C, H, W): accumulated into
-    float* goff;
-    float* gmask;
-    size_t goff_bs, gmask_bs;
-    DcnHaloSel sel;
-    const float* wnorm; // [chunk]: max over the chunk's 72 (tap, channel) columns of ||W[:, c, tap]||_2  (dcn_bwd5_wnorm_kernel)
-    float* part;        // [ns][Co][C * 9] weight-gradient partials
-    float* bpart;       // [ns][Co] bias-gradient partials (nullptr: not wanted)
-    int ns;             // tile streams (= partials)
-    int nty;            // tile rows of 8 output rows
-    int ntiles;         // B * nty * ntx
-};
+// Lane iteration `it` (0..4) of lane half h works on tap (half 0, half 1): (0, 3), (1, 6), (4, 7), (2, 5), (8, none).  The two taps of an
+// iteration sit in DIFFERENT kernel rows: the halves' cells of one ds_add_u32 are then a window row (+-) apart and never the same cell.
+// (First version: (0, 2), (1, 3), (4, 6), (5, 7) -- same row, two columns apart: lane (px + 2, half 0) and lane (px, half 1) hit the same
+// cell in the same instruction whenever their floor()s agree, and the LDS serialises same-address atomics; the kernel was no faster than
+// dcn_bwdin5 although it executes half the vector instructions.)
+__host__ __device__ __forceinline__ int bwd6_tap(int it, int h) {
+    return h == 0 ? (it == 0 ? 0 : it == 1 ? 1 : it == 2 ? 4 : it == 3 ? 2 : it == 4 ? 8 : -1)
+                  : (it == 0 ? 3 : it == 1 ? 6 : it == 2 ? 7 : it == 3 ? 5 : -1);
+}
 
-// Lane iteration `it` (0..4) of lane half h works on tap:  it < 4: 4 (it >> 1) + 2 h + (it & 1);  it == 4: 8 for h = 0, none for h = 1.
-__host__ __device__ __forceinline__ int bwd6_tap(int it, int h) { return it < 4 ? 4 * (it >> 1) + 2 * h + (it & 1) : (h == 0 && it == 4 ? 8 : -1); }
-
-// packed[chunk][mt (3)][part (hi, lo)][o-octet (8)][row (32)][8 o].  Row i of M tile mt lands in accumulator register
+// packed[chunk][mt (3)][part (hi, lo)][o-octet (2 NK)][row (32)][8 o].  Row i of M tile mt lands in accumulator register
 // r = (i & 3) + 4 (i >> 3) of lane half h = (i >> 2) & 1 (D layout of the 32x32 MFMA); that register is to hold channel r & 7 of the tap of
 // lane iteration it = 2 mt + (r >> 3).
+template <int NK>
 __global__ void pack_weights_bwd6_kernel(const float* __restrict__ w, bf16x8* __restrict__ packed, int Co, int C, int nchunks) {
-    const size_t total = (size_t)nchunks * 3 * 8 * 32;
+    const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(idx & 31);
         size_t r = idx >> 5;
-        const int ooct = (int)(r & 7);
-        r >>= 3;
+        const int ooct = (int)(r % (2 * NK));
+        r /= (2 * NK);
         const int mt = (int)(r % 3), chunk = (int)(r / 3);
         const int h = (row >> 2) & 1, reg = (row & 3) + 4 * (row >> 3);
         const int tap = bwd6_tap(2 * mt + (reg >> 3), h), c = 8 * chunk + (reg & 7);
@@ -72,7 +53,7 @@ __global__ void pack_weights_bwd6_kernel(const float* __restrict__ w, bf16x8* __
         }
         bf16x8 hi, lo;
         split8(v, hi, lo);
-        const size_t blk = ((size_t)chunk * 3 + mt) * 2, per = (size_t)8 * 32;
+        const size_t blk = ((size_t)chunk * 3 + mt) * 2, per = (size_t)(2 * NK) * 32;
         packed[blk * per + ooct * 32 + row] = hi;
         packed[(blk + 1) * per + ooct * 32 + row] = lo;
     }
@@ -127,48 +108,118 @@ __device__ __forceinline__ bf16x8 pack8_exact(const f32x16& d, int r0) {
     return o;
 }
 
-// R: halo of the LDS x tile / grad_input window around the 8 x 32 pixel tile.  TERMS: terms of the bf16 products (rvsr_common.h: gemm modes):
-// 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part (col_grad) / the output gradient's lo part (weight gradient); 1 = hi*hi.
-//
-// FOUR waves per workgroup, ONE per SIMD, each with the whole 512-register budget, two pixel rows of the tile per wave (rows w and w + 4,
-// one after the other): the 96 accumulator registers of the chunk's weight gradient exist once per SIMD instead of once per wave -- with
-// eight waves of 256 registers the kernel spilled 90-170 registers (the first build of this file) -- and the transposed gOut operands stay in
-// registers.  What a second wave per SIMD would have hidden is hidden by the wave's own instruction stream instead: the main path of a lane
-// iteration is branch-free (dead lanes add 0 to spread cells, store beyond the buffer view), so hipcc schedules LDS reads, packed math and
-// MFMAs of neighbouring iterations into each other; only the far path (samples beyond the window) is a branch.
-template <int R, int TERMS, int NW>
-__global__ __launch_bounds__(NW * 64) void dcn_bwd6_kernel(const DcnBwd6Params p, const bf16x8* __restrict__ wpack) {
-    constexpr int NK = 4, TH = 8, NT = NW * 64, ROWS = TH / NW;
+
+#ifndef RVSR_ABL6
+#define RVSR_ABL6 0   // scratch ablation builds (tools/build_variant6.sh): bit mask of deleted ingredients, results wrong by construction:
+#endif                // 1 LDS atomics, 2 window flush, 4 corner reads, 8 col_grad MFMAs, 16 grad_offset / grad_mask stores, 32 requests of chunks 1.., 64 packed math
+
+struct DcnBwdIn6Params {
+    DcnGeom d;
+    TView g;            // grad_output view (Co, Ho, Wo), optional fused act'
+    float* gx;          // (B, C, H, W): accumulated into (zero or a partial gradient on entry)
+    float* goff;
+    float* gmask;
+    size_t goff_bs, gmask_bs;
+    DcnHaloSel sel;     // kernel selection on the device (dcn_common.h): every candidate halo is launched, one runs
+    const float* wnorm; // [chunk]: max over the chunk's 72 (tap, channel) columns of ||W[:, c, tap]||_2  (dcn_bwd5_wnorm_kernel)
+};
+
+// TERMS: terms of the bf16 product W^T * gOut (rvsr_common.h: gemm modes): 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part;
+// 1 = hi*hi.  WPS: workgroups the launch bounds promise per CU.
+template <int NK, int R, int TERMS, int WPS>
+__global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Params p, const bf16x8* __restrict__ wpack) {
+    constexpr int TH = 8, NT = TH * 64;
     constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
-    constexpr int WBLK = 2 * (2 * NK) * 32;                        // vectors per M tile: hi + lo
+    constexpr int WBLK = 2 * (2 * NK) * 32;                        // vectors per (chunk, M tile): hi + lo
     constexpr int NXI = (2 * NPOS + NT - 1) / NT;                  // x-tile items (float4 of one position and quad) per thread
     constexpr int NWV = (3 * WBLK + NT - 1) / NT;                  // weight vectors per thread
     static_assert((3 * WBLK) % 64 == 0, "whole waves of weight vectors");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);              // [2 quads][NPOS], zero outside the image
-    int* gwin = reinterpret_cast<int*>(xt + 2 * NPOS);             // [8 channels][NPOS]: the grad_input tile, fixed point
-    bf16x8* wsb = reinterpret_cast<bf16x8*>(gwin + 8 * NPOS);      // [3][WBLK]: the chunk's weight block (whole launch)
-    float* gn_red = reinterpret_cast<float*>(wsb + 3 * WBLK);      // [NW]
-    if (dcn_halo_not_selected(p.sel)) return;   // (uniform)
+    int* gwin = reinterpret_cast<int*>(xt + 2 * NPOS);             // [8 channels][NPOS]: the grad_input tile of this chunk, fixed point
+    bf16x8* wsb = reinterpret_cast<bf16x8*>(gwin + 8 * NPOS);      // [3][WBLK]
+    float* gn_red = reinterpret_cast<float*>(wsb + 3 * WBLK);      // [8 waves]: largest ||gOut[:, px]||^2 of the wave's row
+    if (dcn_halo_not_selected(p.sel)) return;   // (uniform) not the halo the offsets of this call ask for
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int nchunks = d.C >> 3;
-    // workgroup -> (tile stream, chunk): the chunks of a stream on ONE XCD (linear id % 8), streams spread over the XCDs
-    const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-    // (integer divisions run on the vector ALU; readfirstlane brings the uniform results back to SGPRs -- left in VGPRs they made every
-    // buffer descriptor "divergent": a waterfall loop around each of the kernel's ~400 buffer instructions)
-    const int chunk = __builtin_amdgcn_readfirstlane(slot % nchunks), stream = __builtin_amdgcn_readfirstlane(xcd + 8 * (slot / nchunks));
-    const int c0 = chunk * 8, g = chunk;                           // (8 channels per deformable group)
-    const int t_begin = __builtin_amdgcn_readfirstlane((int)((long long)p.ntiles * stream / p.ns));
-    const int t_end = __builtin_amdgcn_readfirstlane((int)((long long)p.ntiles * (stream + 1) / p.ns));
-    const int per_b = p.nty * d.ntx;
+    unsigned sbx, sby, sbz;
+    swizzled_block(sbx, sby, sbz, d.swz);
+    const int tx = __builtin_amdgcn_readfirstlane((int)(sbx % d.ntx)), ty = __builtin_amdgcn_readfirstlane((int)(sbx / d.ntx));
+    const int x0 = tx * 32, y0 = ty * TH, b = __builtin_amdgcn_readfirstlane((int)sbz);
+    const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;         // image coordinates of tile cell (0, 0); stride 1
+    const int nchunks = (d.C + 7) / 8;
     const unsigned HW = (unsigned)(d.H * d.W);
-    const unsigned hw = (unsigned)(d.Ho * d.Wo);
-    const unsigned pl4 = 4u * hw, HW4 = 4u * HW;
-    const bool has_act = p.g.act != nullptr;
+    const size_t hw = (size_t)d.Ho * d.Wo;
+    const int oy = y0 + wave, ox = x0 + lo;
+    const bool px_ok = oy < d.Ho && ox < d.Wo;
+    const size_t pix = (size_t)oy * d.Wo + ox;
+    // raw buffer views of this batch element (32-bit byte offsets: the launcher checks that each spans < 2 GB)
+    const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(d.x + (size_t)b * d.C * HW), gx_rs = buf_view(p.gx + (size_t)b * d.C * HW);
+    const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs), msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
+    const __amdgpu_buffer_rsrc_t goff_rs = buf_view(p.goff + (size_t)b * p.goff_bs), gmsk_rs = buf_view(p.gmask + (size_t)b * p.gmask_bs);
+    const unsigned pl4 = 4u * (unsigned)hw, HW4 = 4u * HW;        // bytes per offset / mask plane, per x plane
+    const unsigned pix4 = px_ok ? 4u * (unsigned)pix : 0u;
+    const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);   // image coordinates of tap (0, 0) at zero offset
 
-    // ---- once per workgroup: weight block (LDS-DMA), window zero, constant operands
-    {
+    // x-tile items of this thread, once per tile: item = (quad, row, col); a position outside the image (or no item) gets a
+    // lane offset beyond the 2 GB view, for which the buffer load returns 0 -- the zero padding costs no clamp and no select
+    unsigned xoff[NXI];
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+        const int it = tid + k * NT;
+        const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
+        const int rr = pos / TC, ss = pos - rr * TC;
+        const int gy = ty0 + rr, gx = tx0 + ss;
+        const bool ok = it < 2 * NPOS && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        xoff[k] = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * quad) * HW) : 0x80000000u;
+    }
+
+    // gOut (x act') of this lane's pixel as bf16 hi / lo MFMA fragments: K = output channels, NK k-steps of 16
+    bf16x8 gh[NK], gl[NK];
+    float gsq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int ol0 = 8 * (2 * ks + hi);
+        float v[8];
+        if (p.g.mode == 0) {  // (uniform)
+            tview_get_plain<8>(p.g, b, ol0, oy, ox, v);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tview_get(p.g, b, ol0 + j, oy, ox);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (px_ok && ol0 + j < d.Co) ? v[j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gsq = __builtin_fmaf(v[j], v[j], gsq);
+        split8(v, gh[ks], gl[ks]);
+    }
+    {   // Gn^2 = the largest squared pixel norm of the tile (read back after the first barrier)
+        gsq = half_sum6(gsq);
+#pragma unroll
+        for (int sft = 16; sft > 0; sft >>= 1) gsq = fmaxf(gsq, __shfl_xor(gsq, sft));
+        if (lane == 0) gn_red[wave] = gsq;
+    }
+    for (int e = tid; e < 8 * NPOS; e += NT) gwin[e] = 0;
+
+    unsigned mg0 = 0x4B400000u;          // 1.5 * 2^23: the magic number of the fixed-point rounding, kept out of the literal encoder
+    asm volatile("" : "+s"(mg0));
+    const f32x2 MAGIC = {__builtin_bit_cast(float, mg0), __builtin_bit_cast(float, mg0)};
+
+    float o_dy[5], o_dx[5], o_m[5];
+    float xv[NXI][4];
+    // requests of a chunk: (dy, dx, mask) of this lane's pixel at its five taps (15 loads), the weight blocks (LDS-DMA: lane l of a wave
+    // lands at M0 + 16 l, no registers), the x tile (registers; committed to LDS once the previous chunk's iterations are done)
+    auto request = [&](int chunk) {
+        const int c0 = chunk * 8, g = c0 / d.cpg;
+        const unsigned ob = (unsigned)(g * 18) * pl4, mb_ = (unsigned)(g * 9) * pl4;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
+            const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
+            o_dy[it] = buf_load(off_rs, pix4 + 2u * tp, ob);
+            o_dx[it] = buf_load(off_rs, pix4 + 2u * tp, ob + pl4);
+            o_m[it] = buf_load(msk_rs, pix4 + tp, mb_);
+        }
         const bf16x8* src = wpack + (size_t)chunk * 3 * WBLK;
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -177,343 +228,173 @@ __global__ __launch_bounds__(NW * 64) void dcn_bwd6_kernel(const DcnBwd6Params p
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e),
                                                  (__attribute__((address_space(3))) void*)(wsb + e), 16, 0, 0);
         }
-    }
-    for (int e = tid; e < 8 * NPOS; e += NT) gwin[e] = 0;
-    // 0/1 selectors of the transposing MFMAs as B operands: lane (j = lo, h = hi) supplies B[k = 8 h + e][j], e < 8
-    //   even: B[k][j] = (j == k), j < 16        odd: B[k][j] = (j == k + 16)
-    bf16x8 sel_e, sel_o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sel_e[e] = (__bf16)((lo == 8 * hi + e) ? 1.f : 0.f);
-        sel_o[e] = (__bf16)((lo == 8 * hi + e + 16) ? 1.f : 0.f);
-    }
-    // x-tile items of this thread: (quad, row, col) are tile-independent
-    int x_it[NXI];   // row << 16 | column << 1 | quad; -1: no item
+        for (int k = 0; k < NXI; ++k)
 #pragma unroll
-    for (int k = 0; k < NXI; ++k) {
-        const int it = tid + k * NT;
-        const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
-        const int rr_ = pos / TC;
-        x_it[k] = it < 2 * NPOS ? (rr_ << 16 | (pos - rr_ * TC) << 1 | quad) : -1;
-    }
-
-    f32x16 gw_acc[2][3];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb) gw_acc[mb][nb] = zero16();
-
-    // ---- requests of a tile (registers).  req_misc: the (dy, dx, mask) triples of the lane's two pixels' five taps + the x tile; req_g: gOut
-    // (+ act) of ONE of its pixels -- the two rows' gOut is requested, and converted to bf16 fragments, one after the other between the two
-    // halves of the window flush, so that at most 64 raw values wait in registers (all 128 at once made hipcc park them in scratch).
-    float graw[32], araw[32];
-    float o_dy[ROWS][5], o_dx[ROWS][5], o_m[ROWS][5];
-    float xv[NXI][4];
-    bf16x8 gh[ROWS][NK], gl[ROWS][NK];
-    float gsq_row[ROWS];
-    auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
-        b = __builtin_amdgcn_readfirstlane(t / per_b);
-        const int rem = t - b * per_b, ty = __builtin_amdgcn_readfirstlane(rem / d.ntx);
-        y0 = ty * TH;
-        x0 = (rem - ty * d.ntx) * 32;
+            for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xoff[k], (unsigned)(c0 + e) * HW4);   // (C % 8 == 0)
     };
-    auto req_g = [&](int t, int rr) {
-        int b, y0, x0;
-        tile_coords(t, b, y0, x0);
-        const __amdgpu_buffer_rsrc_t g_rs = buf_view_2g(p.g.p + (size_t)b * d.Co * hw);
-        const __amdgpu_buffer_rsrc_t a_rs = buf_view_2g((has_act ? p.g.act : p.g.p) + (size_t)b * d.Co * hw);
-        const int oy = y0 + wave + NW * rr, ox = x0 + lo;
-        const bool px_ok = oy < d.Ho && ox < d.Wo;
-        // o = 16 ks + 8 hi + j; whole k-steps beyond Co read as zero (Co % 16 == 0): lane offset beyond the 2 GB view
-        const unsigned vo = px_ok ? 4u * (unsigned)(oy * d.Wo + ox) + (unsigned)(8 * hi) * pl4 : 0x80000000u;
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const unsigned vk = 16 * ks < d.Co ? vo : 0x80000000u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                graw[8 * ks + j] = buf_load(g_rs, vk, (unsigned)(16 * ks + j) * pl4);
-                if (has_act) araw[8 * ks + j] = buf_load(a_rs, vk, (unsigned)(16 * ks + j) * pl4);
-            }
-        }
-    };
-    auto conv_g = [&](int rr) {   // gOut (x act') as bf16 hi / lo fragments: K = output channels, 4 k-steps of 16; squared pixel norm
-        float gsq = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = graw[8 * ks + j];
-                if (has_act) f *= araw[8 * ks + j] > 0.f ? 1.f : p.g.slope;
-                v[j] = f;
-                gsq = __builtin_fmaf(f, f, gsq);
-            }
-            split8(v, gh[rr][ks], gl[rr][ks]);
-        }
-        gsq_row[rr] = gsq;
-    };
-    auto req_misc = [&](int t) {
-        int b, y0, x0;
-        tile_coords(t, b, y0, x0);
-        const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs), msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
-        const unsigned ob = (unsigned)(g * 18) * pl4, mb_ = (unsigned)(g * 9) * pl4;
-#pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const int oy = y0 + wave + NW * rr, ox = x0 + lo;
-            const bool px_ok = oy < d.Ho && ox < d.Wo;
-            const unsigned pv = 4u * (unsigned)(px_ok ? oy * d.Wo + ox : y0 * d.Wo + x0);   // (lanes without a pixel read the tile's first pixel: masked later)
-#pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
-                const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
-                o_dy[rr][it] = buf_load(off_rs, pv + 2u * tp, ob);
-                o_dx[rr][it] = buf_load(off_rs, pv + 2u * tp, ob + pl4);
-                o_m[rr][it] = buf_load(msk_rs, pv + tp, mb_);
-            }
-        }
-        const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(d.x + (size_t)b * d.C * HW);
-        const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
-#pragma unroll
-        for (int k = 0; k < NXI; ++k) {
-            const int gy = ty0 + (x_it[k] >> 16), gx = tx0 + ((x_it[k] >> 1) & 0x7fff);
-            const bool ok = x_it[k] >= 0 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-            const unsigned xo = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * (x_it[k] & 1)) * HW) : 0x80000000u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xo, (unsigned)(c0 + e) * HW4);
-        }
-    };
-    if (t_begin < t_end) {
-        req_misc(t_begin);
-        req_g(t_begin, 0);
-        if (ROWS == 2) {
-            conv_g(0);
-            req_g(t_begin, 1);
-        }
-    }
+    request(0);
 
-    unsigned mg0 = 0x4B400000u;          // 1.5 * 2^23: the magic number of the fixed-point rounding, kept out of the literal encoder
-    asm volatile("" : "+s"(mg0));
-    const f32x2 MAGIC = {__builtin_bit_cast(float, mg0), __builtin_bit_cast(float, mg0)};
-
-    for (int t = t_begin; t < t_end; ++t) {
-        int b, y0, x0;
-        tile_coords(t, b, y0, x0);
-        const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
-        const __amdgpu_buffer_rsrc_t gx_rs = buf_view(p.gx + (size_t)b * d.C * HW);
-        const __amdgpu_buffer_rsrc_t goff_rs = buf_view(p.goff + (size_t)b * p.goff_bs), gmsk_rs = buf_view(p.gmask + (size_t)b * p.gmask_bs);
-
-        conv_g(ROWS - 1);   // (two rows per wave: row 0 was converted between the two halves of the previous tile's flush)
-        float gsq_max = half_sum6(gsq_row[0]);
-        if (ROWS == 2) gsq_max = fmaxf(gsq_max, half_sum6(gsq_row[ROWS - 1]));
-        {   // Gn^2 = the largest squared pixel norm of the tile (read back after the barrier)
-#pragma unroll
-            for (int sft = 16; sft > 0; sft >>= 1) gsq_max = fmaxf(gsq_max, __shfl_xor(gsq_max, sft));
-            if (lane == 0) gn_red[wave] = gsq_max;
-        }
-        // ---- commit the x tile
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * 8;
+        const int g = c0 / d.cpg;
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int it = tid + k * NT;
             if (it < 2 * NPOS) xt[it] = make_float4(xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (first tile: this wave's share of the weight DMA has landed)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA has landed
         __syncthreads();
 
-        // fixed-point scale (dcn5_kernels.hip header): |contribution| * S <= 0.995 * 2^31 / 2304
+        // fixed-point scale of this chunk (dcn5_kernels.hip header): |contribution| * S <= 0.995 * 2^31 / 2304
         float S, invS;
         {
             float g2 = gn_red[0];
 #pragma unroll
-            for (int k = 1; k < NW; ++k) g2 = fmaxf(g2, gn_red[k]);
+            for (int k = 1; k < TH; ++k) g2 = fmaxf(g2, gn_red[k]);
             const float bound = 1.002f * p.wnorm[chunk] * sqrtf(g2);
             S = bound > 0.f ? 927407.f / bound : 0.f;
             invS = bound > 0.f ? bound * (1.f / 927407.f) : 0.f;
         }
-
+        const bool first_of_group = c0 % d.cpg == 0;   // (uniform) later chunks of a deformable group (cpg > 8) add to its planes
 #pragma unroll
-        for (int rr = 0; rr < ROWS; ++rr) {
-            const int oy = y0 + wave + NW * rr, ox = x0 + lo;
-            const bool px_ok = oy < d.Ho && ox < d.Wo;
-            const unsigned pix4 = px_ok ? 4u * (unsigned)(oy * d.Wo + ox) : 0u;
-            const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
-            // ---- gOut transposed by the matrix core: G[i = pixel][j = o] -> registers (lane = o, register = pixel) = the A operands of the
-            // weight-gradient GEMM: ag[mb][ks][hi, lo]
-            bf16x8 ag[2][2][2];
+        for (int mt = 0; mt < 3; ++mt) {
+            f32x16 acc = zero16();
+            const bf16x8* wb_hi = wsb + mt * WBLK;
+            const bf16x8* wb_lo = wb_hi + (2 * NK) * 32;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                f32x16 th = mfma_bf16(gh[rr][2 * mb], sel_e, zero16());
-                th = mfma_bf16(gh[rr][2 * mb + 1], sel_o, th);
-                ag[mb][0][0] = pack8_exact(th, 0);
-                ag[mb][1][0] = pack8_exact(th, 8);
-                if (TERMS >= 3) {
-                    f32x16 tl = mfma_bf16(gl[rr][2 * mb], sel_e, zero16());
-                    tl = mfma_bf16(gl[rr][2 * mb + 1], sel_o, tl);
-                    ag[mb][0][1] = pack8_exact(tl, 0);
-                    ag[mb][1][1] = pack8_exact(tl, 8);
-                }
+            for (int ks = 0; ks < NK; ++ks) {
+                const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo];
+                if (RVSR_ABL6 & 8) { acc[ks] += (float)ah[0] * (float)gh[ks][0] + (float)gl[ks][1]; acc[ks + 8] += (float)ah[1]; continue; }
+                acc = mfma_bf16(ah, gh[ks], acc);
+                if (TERMS >= 2) acc = mfma_bf16(ah, gl[ks], acc);
+                if (TERMS >= 3) acc = mfma_bf16(wb_lo[(2 * ks + hi) * 32 + lo], gh[ks], acc);
             }
-            f32x16 dt_h, dt_l;   // column values of two lane iterations, transposed: D[i = pixel][j = 16 (it & 1) + 8 h + ch]
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) {
-                f32x16 acc = zero16();
-                const bf16x8* wb_hi = wsb + mt * WBLK;
-                const bf16x8* wb_lo = wb_hi + (2 * NK) * 32;
+            for (int s = 0; s < 2; ++s) {
+                const int it = 2 * mt + s;
+                if (it >= 5) continue;   // (compile time)
+                const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
+                const bool has_tap = it < 4 || hi == 0;
+                const int tap = hi ? t1 : t0;
+                const bool act_lane = px_ok && has_tap;
+                // lanes without a pixel / a tap: zero offset, zero mask (their col_grad is 0 or belongs to zero weight rows)
+                const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
+                float m = o_m[it];
+                if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
+                const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
+                // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616, 722-737)
+                const float y = (by + kyf) + dy, x = (bx + kxf) + dx;
+                const float fy = floorf(y), fx = floorf(x);
+                const int yi = (int)fy, xi = (int)fx;
+                const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
+                const int r0 = yi - ty0, s0 = xi - tx0;   // tile coordinates of the top-left corner
+                const bool in_tile = act_lane && (unsigned)r0 < (unsigned)(TR - 1) && (unsigned)s0 < (unsigned)(TC - 1);
+                const bool inside = y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W;
+                const bool far = !in_tile && inside && act_lane;   // beyond the halo: global gather / atomics with the full rule set
+                const int pos0 = in_tile ? r0 * TC + s0 : lo;      // (dead lanes: distinct cells of the first row; they add 0)
+                const float ml = in_tile ? m : 0.f;               // dead and far lanes contribute nothing on the main path
+                const f32x2 L2 = {ly, lx}, MS = {ml, ml * S};
+                const f32x2 W01 = {hy * hx, hy * lx}, W23 = {ly * hx, ly * lx};
+                f32x2 gm2 = {0.f, 0.f}, gy2 = {0.f, 0.f}, gx2 = {0.f, 0.f};
+                int* wq = gwin + pos0;
 #pragma unroll
-                for (int ks = 0; ks < NK; ++ks) {
-                    const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo];
-                    acc = mfma_bf16(ah, gh[rr][ks], acc);
-                    if (TERMS >= 2) acc = mfma_bf16(ah, gl[rr][ks], acc);
-                    if (TERMS >= 3) acc = mfma_bf16(wb_lo[(2 * ks + hi) * 32 + lo], gh[rr][ks], acc);
-                }
+                for (int q = 0; q < 2; ++q) {
+                    const float4* xq = xt + q * NPOS + ((RVSR_ABL6 & 4) ? 0 : pos0);
+                    float4 a00 = xq[0], a01 = xq[1], a10 = xq[TC], a11 = xq[TC + 1];
+                    if (RVSR_ABL6 & 4) { a00 = make_float4(ly, lx, hy, hx); a01 = make_float4(lx, ly, hx, hy); a10 = a01; a11 = a00; }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int it = 2 * mt + s;
-                    if (it >= 5) continue;   // (compile time)
-                    const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
-                    const bool has_tap = it < 4 || hi == 0;
-                    const int tap = hi ? t1 : t0;
-                    const bool act_lane = px_ok && has_tap;
-                    const float dy = act_lane ? o_dy[rr][it] : 0.f, dx = act_lane ? o_dx[rr][it] : 0.f;
-                    float m = o_m[rr][it];
-                    if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
-                    const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
-                    // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616, 722-737)
-                    const float y = (by + kyf) + dy, x = (bx + kxf) + dx;
-                    const float fy = floorf(y), fx = floorf(x);
-                    const int yi = (int)fy, xi = (int)fx;
-                    const float ly = y - fy, lx = x - fx, hy = 1.f - ly, hx = 1.f - lx;
-                    const int r0 = yi - ty0, s0 = xi - tx0;
-                    const bool in_tile = act_lane && (unsigned)r0 < (unsigned)(TR - 1) && (unsigned)s0 < (unsigned)(TC - 1);
-                    const bool inside = y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W;
-                    const bool far = !in_tile && inside && act_lane;   // beyond the window: global gather / atomics with the full rule set
-                    const int pos0 = in_tile ? r0 * TC + s0 : lo;      // (dead lanes: distinct cells of the first row; they add 0)
-                    const float ml = in_tile ? m : 0.f;               // dead and far lanes contribute nothing on the main path
-                    const f32x2 L2 = {ly, lx}, MS = {ml, ml * S};
-                    const f32x2 W01 = {hy * hx, hy * lx}, W23 = {ly * hx, ly * lx};
-                    f32x2 gm2 = {0.f, 0.f}, gy2 = {0.f, 0.f}, gx2 = {0.f, 0.f};
-                    float colv[8];
-                    int* wq = gwin + pos0;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float4* xq = xt + q * NPOS + pos0;
-                        const float4 a00 = xq[0], a01 = xq[1], a10 = xq[TC], a11 = xq[TC + 1];
-#pragma unroll
-                        for (int ph = 0; ph < 2; ++ph) {       // channel pairs (2 pr, 2 pr + 1), pr = 2 q + ph
-                            const int pr = 2 * q + ph;
-                            const f32x2 c00 = ph ? f32x2{a00.z, a00.w} : f32x2{a00.x, a00.y};
-                            const f32x2 c01 = ph ? f32x2{a01.z, a01.w} : f32x2{a01.x, a01.y};
-                            const f32x2 c10 = ph ? f32x2{a10.z, a10.w} : f32x2{a10.x, a10.y};
-                            const f32x2 c11 = ph ? f32x2{a11.z, a11.w} : f32x2{a11.x, a11.y};
-                            const f32x2 cg = {acc[8 * s + 2 * pr], acc[8 * s + 2 * pr + 1]};
-                            const f32x2 Bv = pk_sub(c01, c00), Cv = pk_sub(c10, c00), Dv = pk_sub(pk_sub(c11, c01), Cv);
-                            const f32x2 dxv = pk_fma_x(L2, Dv, Bv), dyv = pk_fma_y(L2, Dv, Cv);   // d val / d x, d val / d y
-                            const f32x2 val = pk_fma_y(L2, dxv, pk_fma_x(L2, Cv, c00));          // bilinear(x)
-                            gm2 = pk_fma(cg, val, gm2);
-                            const f32x2 tv = pk_mul_x(MS, cg);                                    // col_grad * mask
-                            gy2 = pk_fma(dyv, tv, gy2);
-                            gx2 = pk_fma(dxv, tv, gx2);
-                            const f32x2 cv = pk_mul_x(MS, val);                                   // the column value of the weight gradient
-                            colv[2 * pr] = cv.x; colv[2 * pr + 1] = cv.y;
-                            // ---- scatter: 8 LDS integer atomics per channel pair into the shared window (unconditional)
-                            const f32x2 ts = pk_mul_y(MS, cg);                                    // col_grad * mask * S
-                            const f32x2 u00 = pk_fma_x(W01, ts, MAGIC), u01 = pk_fma_y(W01, ts, MAGIC);
-                            const f32x2 u10 = pk_fma_x(W23, ts, MAGIC), u11 = pk_fma_y(W23, ts, MAGIC);
-                            // (.x / .y spelled out: `u00[e]` under an unrolled e compiled to element 0 twice with this hipcc)
-                            int* q0 = wq + (2 * pr) * NPOS;
-                            int* q1 = q0 + NPOS;
-                            lds_add_i32_6(q0, (int)(__builtin_bit_cast(unsigned, u00.x) - 0x4B400000u));
-                            lds_add_i32_6(q0 + 1, (int)(__builtin_bit_cast(unsigned, u01.x) - 0x4B400000u));
-                            lds_add_i32_6(q0 + TC, (int)(__builtin_bit_cast(unsigned, u10.x) - 0x4B400000u));
-                            lds_add_i32_6(q0 + TC + 1, (int)(__builtin_bit_cast(unsigned, u11.x) - 0x4B400000u));
-                            lds_add_i32_6(q1, (int)(__builtin_bit_cast(unsigned, u00.y) - 0x4B400000u));
-                            lds_add_i32_6(q1 + 1, (int)(__builtin_bit_cast(unsigned, u01.y) - 0x4B400000u));
-                            lds_add_i32_6(q1 + TC, (int)(__builtin_bit_cast(unsigned, u10.y) - 0x4B400000u));
-                            lds_add_i32_6(q1 + TC + 1, (int)(__builtin_bit_cast(unsigned, u11.y) - 0x4B400000u));
-                        }
+                    for (int ph = 0; ph < 2; ++ph) {       // channel pairs (2 pr, 2 pr + 1), pr = 2 q + ph
+                        const int pr = 2 * q + ph;
+                        const f32x2 c00 = ph ? f32x2{a00.z, a00.w} : f32x2{a00.x, a00.y};
+                        const f32x2 c01 = ph ? f32x2{a01.z, a01.w} : f32x2{a01.x, a01.y};
+                        const f32x2 c10 = ph ? f32x2{a10.z, a10.w} : f32x2{a10.x, a10.y};
+                        const f32x2 c11 = ph ? f32x2{a11.z, a11.w} : f32x2{a11.x, a11.y};
+                        const f32x2 cg = {acc[8 * s + 2 * pr], acc[8 * s + 2 * pr + 1]};
+                        const f32x2 Bv = pk_sub(c01, c00), Cv = pk_sub(c10, c00), Dv = pk_sub(pk_sub(c11, c01), Cv);
+                        const f32x2 dxv = pk_fma_x(L2, Dv, Bv), dyv = pk_fma_y(L2, Dv, Cv);   // d val / d x, d val / d y
+                        const f32x2 val = pk_fma_y(L2, dxv, pk_fma_x(L2, Cv, c00));          // bilinear(x)
+                        gm2 = pk_fma(cg, val, gm2);
+                        const f32x2 tv = pk_mul_x(MS, cg);                                    // col_grad * mask
+                        gy2 = pk_fma(dyv, tv, gy2);
+                        gx2 = pk_fma(dxv, tv, gx2);
+                        // ---- scatter: 8 LDS integer atomics per channel pair into the shared window (unconditional: dead lanes add 0)
+                        const f32x2 ts = pk_mul_y(MS, cg);                                    // col_grad * mask * S
+                        const f32x2 u00 = pk_fma_x(W01, ts, MAGIC), u01 = pk_fma_y(W01, ts, MAGIC);
+                        const f32x2 u10 = pk_fma_x(W23, ts, MAGIC), u11 = pk_fma_y(W23, ts, MAGIC);
+                        // (__float_as_uint, not __builtin_bit_cast(unsigned, u00.y): this hipcc compiles the bit_cast of a vector ELEMENT to element 0 -- /tmp test, r05_notes.md)
+                        int* q0 = wq + (2 * pr) * NPOS;
+                        int* q1 = q0 + NPOS;
+                        if (RVSR_ABL6 & 1) { gm2 = pk_fma(u00, u01, gm2); gy2 = pk_fma(u10, u11, gy2); continue; }
+                        lds_add_i32_6(q0, (int)(__float_as_uint(u00.x) - 0x4B400000u));
+                        lds_add_i32_6(q0 + 1, (int)(__float_as_uint(u01.x) - 0x4B400000u));
+                        lds_add_i32_6(q0 + TC, (int)(__float_as_uint(u10.x) - 0x4B400000u));
+                        lds_add_i32_6(q0 + TC + 1, (int)(__float_as_uint(u11.x) - 0x4B400000u));
+                        lds_add_i32_6(q1, (int)(__float_as_uint(u00.y) - 0x4B400000u));
+                        lds_add_i32_6(q1 + 1, (int)(__float_as_uint(u01.y) - 0x4B400000u));
+                        lds_add_i32_6(q1 + TC, (int)(__float_as_uint(u10.y) - 0x4B400000u));
+                        lds_add_i32_6(q1 + TC + 1, (int)(__float_as_uint(u11.y) - 0x4B400000u));
                     }
-                    float gm_s = gm2.x + gm2.y, gy_s = gy2.x + gy2.y, gx_s = gx2.x + gx2.y;
-                    gm_s = in_tile ? gm_s : 0.f;
-                    if (far) {   // ---- rare: the whole (pixel, tap) from global memory with the reference's rule set, plain arithmetic
-                        const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
-                        const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1, cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
-                        const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
-                        const float z00 = (vy0 && vx0) ? 1.f : 0.f, z01 = (vy0 && vx1) ? 1.f : 0.f;
-                        const float z10 = (vy1 && vx0) ? 1.f : 0.f, z11 = (vy1 && vx1) ? 1.f : 0.f;
-                        const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
-                        const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
-                        float* gp = p.gx + ((size_t)b * d.C + c0) * HW;
-                        gm_s = gy_s = gx_s = 0.f;
+                }
+                float gm_s = gm2.x + gm2.y, gy_s = gy2.x + gy2.y, gx_s = gx2.x + gx2.y;
+                gm_s = in_tile ? gm_s : 0.f;
+                if (far) {   // ---- rare: the whole (pixel, tap) from global memory with the reference's rule set, plain arithmetic
+                    const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                    const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1, cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                    const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                    const float z00 = (vy0 && vx0) ? 1.f : 0.f, z01 = (vy0 && vx1) ? 1.f : 0.f;
+                    const float z10 = (vy1 && vx0) ? 1.f : 0.f, z11 = (vy1 && vx1) ? 1.f : 0.f;
+                    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+                    const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
+                    float* gp = p.gx + ((size_t)b * d.C + c0) * HW;
+                    gm_s = gy_s = gx_s = 0.f;
 #pragma unroll 1
-                        for (int e = 0; e < 8; ++e) {   // (a real loop: ten unrolled copies of this block made the register allocator spill on the main path)
-                            const float* qp = pl + (size_t)e * HW;
-                            const float c00 = qp[i00] * z00, c01 = qp[i01] * z01, c10 = qp[i10] * z10, c11 = qp[i11] * z11;
-                            const float Bq = c01 - c00, Cq = c10 - c00, Dq = (c11 - c01) - Cq;
-                            const float dxq = Bq + ly * Dq, dyq = Cq + lx * Dq, vq = (c00 + ly * Cq) + lx * dxq;
-                            float cgq = acc[8 * s];
+                    for (int e = 0; e < 8; ++e) {   // (a real loop: unrolled copies of this block in every iteration cost registers on the main path)
+                        const float* qp = pl + (size_t)e * HW;
+                        const float c00 = qp[i00] * z00, c01 = qp[i01] * z01, c10 = qp[i10] * z10, c11 = qp[i11] * z11;
+                        const float Bq = c01 - c00, Cq = c10 - c00, Dq = (c11 - c01) - Cq;
+                        const float dxq = Bq + ly * Dq, dyq = Cq + lx * Dq, vq = (c00 + ly * Cq) + lx * dxq;
+                        float cgq = acc[8 * s];
 #pragma unroll
-                            for (int j = 1; j < 8; ++j) cgq = e == j ? acc[8 * s + j] : cgq;
-                            const float tq = cgq * m;
-                            gm_s += cgq * vq;
-                            gy_s += dyq * tq;
-                            gx_s += dxq * tq;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) colv[j] = e == j ? vq * m : colv[j];
-                            float* gq = gp + (size_t)e * HW;
-                            if (z00 * w00 != 0.f) atomicAdd(gq + i00, w00 * tq);
-                            if (z01 * w01 != 0.f) atomicAdd(gq + i01, w01 * tq);
-                            if (z10 * w10 != 0.f) atomicAdd(gq + i10, w10 * tq);
-                            if (z11 * w11 != 0.f) atomicAdd(gq + i11, w11 * tq);
-                        }
-                    }
-                    {   // grad_offset / grad_mask of (pixel, tap): this lane holds the sum over the group's 8 channels; dead lanes store beyond the view
-                        if (d.mask_logit) gm_s *= m * (1.f - m);
-                        const unsigned tp = (unsigned)tap * pl4;
-                        const unsigned so = act_lane ? pix4 + 2u * tp : 0xfffffffcu, sm = act_lane ? pix4 + tp : 0xfffffffcu;
-                        buf_store(goff_rs, so, (unsigned)(g * 18) * pl4, gy_s);
-                        buf_store(goff_rs, so, (unsigned)(g * 18) * pl4 + pl4, gx_s);
-                        buf_store(gmsk_rs, sm, (unsigned)(g * 9) * pl4, gm_s);
-                    }
-                    // ---- the column values of this iteration into the transposing MFMAs (spare slot of iteration 4, half 1: the ones column of
-                    // the bias gradient)
-                    if (it == 4) colv[0] = hi ? (px_ok ? 1.f : 0.f) : colv[0];
-                    bf16x8 ch_, cl_;
-                    split8(colv, ch_, cl_);
-                    if (s == 0) {
-                        dt_h = mfma_bf16(ch_, sel_e, zero16());
-                        if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_e, zero16());
-                    } else {
-                        dt_h = mfma_bf16(ch_, sel_o, dt_h);
-                        if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_o, dt_l);
+                        for (int j = 1; j < 8; ++j) cgq = e == j ? acc[8 * s + j] : cgq;
+                        const float tq = cgq * m;
+                        gm_s += cgq * vq;
+                        gy_s += dyq * tq;
+                        gx_s += dxq * tq;
+                        float* gq = gp + (size_t)e * HW;
+                        if (z00 * w00 != 0.f) atomicAdd(gq + i00, w00 * tq);
+                        if (z01 * w01 != 0.f) atomicAdd(gq + i01, w01 * tq);
+                        if (z10 * w10 != 0.f) atomicAdd(gq + i10, w10 * tq);
+                        if (z11 * w11 != 0.f) atomicAdd(gq + i11, w11 * tq);
                     }
                 }
-                // ---- weight gradient of n-block mt (two lane iterations): gw_acc[mb][mt] += gOut^T[mb] x col, K = this row's 32 pixels
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 bh = pack8_exact(dt_h, 8 * ks);
-                    bf16x8 bl = bh;
-                    if (TERMS >= 2) bl = pack8_exact(dt_l, 8 * ks);
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
-                        gw_acc[mb][mt] = mfma_bf16(ag[mb][ks][0], bh, gw_acc[mb][mt]);
-                        if (TERMS >= 2) gw_acc[mb][mt] = mfma_bf16(ag[mb][ks][0], bl, gw_acc[mb][mt]);
-                        if (TERMS >= 3) gw_acc[mb][mt] = mfma_bf16(ag[mb][ks][1], bh, gw_acc[mb][mt]);
+                {   // grad_offset / grad_mask of (pixel, tap): this lane holds the sum over the chunk's 8 channels; dead lanes store beyond the view
+                    if (d.mask_logit) gm_s *= m * (1.f - m);
+                    const unsigned tp = (unsigned)tap * pl4;
+                    const unsigned so = act_lane ? pix4 + 2u * tp : 0xfffffffcu, sm = act_lane ? pix4 + tp : 0xfffffffcu;
+                    const unsigned go_ = (unsigned)(g * 18) * pl4, gk = (unsigned)(g * 9) * pl4;
+                    if (RVSR_ABL6 & 16) { if (gy_s + gx_s + gm_s == 12345.678f) buf_store(goff_rs, so, go_, gy_s); }
+                    else if (first_of_group) {
+                        buf_store(goff_rs, so, go_, gy_s);
+                        buf_store(goff_rs, so, go_ + pl4, gx_s);
+                        buf_store(gmsk_rs, sm, gk, gm_s);
+                    } else if (act_lane) {   // a later chunk of the same deformable group (cpg > 8)
+                        buf_store(goff_rs, so, go_, buf_load(goff_rs, so, go_) + gy_s);
+                        buf_store(goff_rs, so, go_ + pl4, buf_load(goff_rs, so, go_ + pl4) + gx_s);
+                        buf_store(gmsk_rs, sm, gk, buf_load(gmsk_rs, sm, gk) + gm_s);
                     }
                 }
             }
         }
         __syncthreads();
-        const bool more = t + 1 < t_end;   // (uniform)
-        if (more) {                         // the next tile's requests fly while the window is flushed
-            req_misc(t + 1);
-            req_g(t + 1, 0);
-        }
-        // ---- flush: wave w owns channels c0 + w and c0 + w + 4; one global atomic per touched cell inside the image, cell back to zero
-#pragma unroll
-        for (int cc = 0; cc < 8 / NW; ++cc) {
-            const int ch = wave + NW * cc;
-            const unsigned cpl = (unsigned)(c0 + ch) * HW4;
-            int* gc = gwin + ch * NPOS;
-            for (int base = lane; base < NPOS; base += 256) {   // four cells per round trip
+        if (chunk + 1 < nchunks && !(RVSR_ABL6 & 32)) request(chunk + 1);   // (uniform) in flight while the window is flushed
+        // ---- flush: wave w owns channel c0 + w; one global atomic per touched cell inside the image (the halos of
+        // neighbouring workgroups overlap), cell back to zero for the next chunk
+        {
+            const unsigned cpl = (unsigned)(c0 + wave) * HW4;
+            int* gc = gwin + wave * NPOS;
+            const bool ch_ok = c0 + wave < d.C;
+            for (int base = lane; base < ((RVSR_ABL6 & 2) ? 0 : NPOS); base += 256) {   // four cells per round trip
                 int v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = base + 64 * j < NPOS ? gc[base + 64 * j] : 0;
@@ -524,20 +405,403 @@ __global__ __launch_bounds__(NW * 64) void dcn_bwd6_kernel(const DcnBwd6Params p
                         gc[pos] = 0;
                         const int r = pos / TC, s = pos - r * TC;
                         const int yy = ty0 + r, xx = tx0 + s;
-                        if (yy >= 0 && yy < d.H && xx >= 0 && xx < d.W)
+                        if (ch_ok && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W)
                             buf_atomic_add(gx_rs, 4u * (unsigned)(yy * d.W + xx), cpl, (float)v[j] * invS);
                     }
                 }
             }
-            if (ROWS == 2 && cc == 0 && more) {
-                conv_g(0);
-                req_g(t + 1, 1);
+        }
+        // (the barrier after the next commit orders this flush before the next chunk's atomics)
+    }
+}
+
+// (dcn5_kernels.hip)
+__global__ void dcn_bwd5_wnorm_kernel(const float* __restrict__ w, float* __restrict__ wn, int Co, int C);
+
+static int nk6_of(int Co) { return Co <= 16 ? 1 : (Co <= 32 ? 2 : (Co <= 64 ? 4 : 8)); }
+size_t rvsr_dcn_bwdin6_workspace_bytes(int Co, int C) {
+    // weight image + per-chunk column norms + the probe's counters
+    return (size_t)((C + 7) / 8) * 3 * 2 * (2 * nk6_of(Co)) * 32 * 16 + (((size_t)((C + 7) / 8) * 4 + 255) & ~(size_t)255) + 256;
+}
+
+template <int NK, int R>
+static int launch_bwdin6(const DcnBwdIn6Params& p, const bf16x8* wpack, hipStream_t st) {
+    constexpr int TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
+    constexpr size_t lds = (size_t)NPOS * (2 * 16 + 8 * 4) + (size_t)3 * 2 * (2 * NK) * 32 * 16 + 8 * sizeof(float);
+    constexpr int WPS = lds <= 80 * 1024 && NK <= 4 ? 2 : 1;   // (two workgroups per CU where LDS allows: the register budget follows)
+    auto k = dcn_bwdin6_kernel<NK, R, 3, WPS>;
+    if constexpr (NK >= 4) {   // reduced-term products (gemm modes 2 / 3): the kernels of the nf64 / nf128 packs
+        const int nt = rvsr_gemm_terms();
+        if (nt == 2) k = dcn_bwdin6_kernel<NK, R, 2, WPS>;
+        if (nt == 1) k = dcn_bwdin6_kernel<NK, R, 1, WPS>;
+    }
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin6: cannot reserve %zu B of LDS", lds);
+    const DcnGeom& d = p.d;
+    dim3 grid(d.ntx * ((d.Ho + TH - 1) / TH), 1, d.B);
+    hipLaunchKernelGGL(k, grid, dim3(TH * 64), lds, st, p, wpack);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin6 launch: %s", hipGetErrorString(e));
+    return RVSR_OK;
+}
+
+template <int NK>
+static int launch_bwdin6_halo(const DcnBwdIn6Params& p, const bf16x8* wpack, int halo, hipStream_t st) {
+    if (halo <= 2) return launch_bwdin6<NK, 2>(p, wpack, st);
+    if constexpr (NK <= 4) if (halo <= 4) return launch_bwdin6<NK, 4>(p, wpack, st);   // (77 KB: the largest window that still fits twice per CU)
+    if (halo <= 5) return launch_bwdin6<NK, 5>(p, wpack, st);
+    if (halo <= 8) return launch_bwdin6<NK, 8>(p, wpack, st);
+    if constexpr (NK <= 4) return launch_bwdin6<NK, 12>(p, wpack, st);   // (12 px + the 48 KB weight block of NK = 8 exceed 160 KB)
+    return launch_bwdin6<NK, 8>(p, wpack, st);
+}
+
+// halo < 0: selected on the device from the offsets (probe + one launch per candidate halo, no host round trip); same protocol as
+// rvsr_launch_dcn_bwdin5, which stays the kernel of geometries this one does not cover (RVSR_ERR_UNSUPPORTED).
+int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo,
+                           const unsigned* probe_in) {
+    if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < rvsr_dcn_bwdin6_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
+    // 32-bit byte offsets into one batch element's planes (x through a 2 GB view: bit 31 marks the zero padding)
+    const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)d.C ? (size_t)(d.C / d.cpg) * 18 : (size_t)d.C;
+    if (planes * (size_t)d.H * d.W * sizeof(float) >= ((size_t)1 << 31) || planes * (size_t)d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
+        return RVSR_ERR_UNSUPPORTED;
+    const int NK = nk6_of(d.Co), nchunks = (d.C + 7) / 8;
+    const size_t wbytes = (size_t)nchunks * 3 * 2 * (2 * NK) * 32 * 16;
+    bf16x8* wpack = (bf16x8*)workspace;
+    float* wnorm = (float*)((unsigned char*)workspace + wbytes);
+    unsigned* cnt = (unsigned*)((unsigned char*)workspace + wbytes + (((size_t)nchunks * 4 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(dcn_bwd5_wnorm_kernel, dim3(nchunks), dim3(576), 0, st, weight, wnorm, d.Co, d.C);
+    const size_t total = (size_t)nchunks * 3 * (2 * NK) * 32;
+    const dim3 pg((unsigned)((total + 255) / 256)), pb(256);
+    switch (NK) {
+        case 1: hipLaunchKernelGGL(pack_weights_bwd6_kernel<1>, pg, pb, 0, st, weight, wpack, d.Co, d.C, nchunks); break;
+        case 2: hipLaunchKernelGGL(pack_weights_bwd6_kernel<2>, pg, pb, 0, st, weight, wpack, d.Co, d.C, nchunks); break;
+        case 4: hipLaunchKernelGGL(pack_weights_bwd6_kernel<4>, pg, pb, 0, st, weight, wpack, d.Co, d.C, nchunks); break;
+        default: hipLaunchKernelGGL(pack_weights_bwd6_kernel<8>, pg, pb, 0, st, weight, wpack, d.Co, d.C, nchunks); break;
+    }
+    DcnBwdIn6Params p;
+    p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
+    p.sel = dcn_halo_always(); p.wnorm = wnorm;
+#define BWDIN6_DISPATCH(HALO)                                                   \
+    switch (NK) {                                                               \
+        case 1: rc = launch_bwdin6_halo<1>(p, wpack, HALO, st); break;          \
+        case 2: rc = launch_bwdin6_halo<2>(p, wpack, HALO, st); break;          \
+        case 4: rc = launch_bwdin6_halo<4>(p, wpack, HALO, st); break;          \
+        default: rc = launch_bwdin6_halo<8>(p, wpack, HALO, st); break;         \
+    }
+    int rc = RVSR_OK;
+    if (halo >= 0) {
+        BWDIN6_DISPATCH(halo);
+        return rc;
+    }
+    const int oplanes = (d.C / d.cpg) * 18, nrow = (d.Ho + 15) / 16;
+    const size_t nprobe = (size_t)d.B * oplanes * nrow * d.Wo;
+    if (probe_in != nullptr) {
+        cnt = const_cast<unsigned*>(probe_in);   // the forward of this layer already counted these offsets (rvsr_dcn_pack_forward's probe)
+    } else {
+        if (hipMemsetAsync(cnt, 0, DCN_PROBE_COUNTERS * sizeof(unsigned), st) != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn backward: memset of the probe counters failed");
+        rvsr_launch_dcn_offset_probe(d, cnt, st);
+    }
+    // A sample beyond the halo costs 32 global gathers + 32 global atomics, a larger halo costs staging and flush work in proportion to its
+    // cells (585 / 817 / 945 / 1377 / 2065): switch up as soon as 2 % of the offset components leave the smaller window.
+    const unsigned thr = (unsigned)(nprobe * (size_t)2 / 100) + 1;
+    const bool has12 = NK <= 4;
+    p.sel.probe = cnt;
+    p.sel.thr_ge = p.sel.thr_lt = thr;
+    // R = 2: few components beyond 2.5 px; R = 4: else, few beyond 3.5 px; R = 5: else, few beyond 5.5; R = 8: else, few beyond 8.5 (or no
+    // larger window); R = 12: the rest.  The counters are monotone, so the chain is a partition.
+    if (has12) {
+        const int halos[5] = {2, 4, 5, 8, 12}, ge[5] = {-1, 0, 1, 2, 4}, lt[5] = {0, 1, 2, 4, -1};
+        for (int k = 0; k < 5; ++k) {
+            p.sel.ge = ge[k]; p.sel.lt = lt[k];
+            BWDIN6_DISPATCH(halos[k]);
+            if (rc != RVSR_OK) return rc;
+        }
+    } else {
+        const int halos[3] = {2, 5, 8}, ge[3] = {-1, 0, 2}, lt[3] = {0, 2, -1};
+        for (int k = 0; k < 3; ++k) {
+            p.sel.ge = ge[k]; p.sel.lt = lt[k];
+            BWDIN6_DISPATCH(halos[k]);
+            if (rc != RVSR_OK) return rc;
+        }
+    }
+#undef BWDIN6_DISPATCH
+    return rc;
+}
+
+// ==========================================================================================================================================
+// dcn_bwdw6: weight / bias gradient of the modulated DCN (the reference's im2col recompute + `gW += gOut col^T` GEMM + bias GEMV,
+// deform_conv_cuda.cpp:647-671, kernel.cu:571-633), sixth generation.
+//
+// dcn_bwdw4 (dcn_bwdw4.inc) rebuilt the 72 x 128 column tile of a chunk in LDS through 2-byte stores, three barriers per tile, one
+// workgroup per CU: 2.7 ms per L1 launch for the GEMM the forward does in 1.2 ms together with everything else.  Here
+//   * lane (pixel, half) samples one (pixel, tap) for the chunk's 8 channels per lane iteration (the tap pairing of dcn_bwdin6), mask
+//     folded into the four corner weights, packed f32 blend;
+//   * the GEMM needs PIXELS along the MFMA's K (register) dimension for both operands, the sampling produces them along the LANE
+//     dimension: the matrix core transposes.  D = A x [I16 | 0] (+ A' x [0 | I16]) with a 0/1 selector as B operand moves
+//     A[i = pixel][k = column] into D[i = pixel][j = column], whose register layout is (lane = j, register = i) -- exact (one non-zero
+//     product per output, f32 accumulate), no LDS tile, no 2-byte stores.  The same two instructions turn the gOut fragments
+//     (lane = pixel, K = output channel) into the A operand (lane = output channel, K = pixel).  The pixel order along K is whatever the
+//     D layout makes it -- the same for both operands, which is all a dot product needs;
+//   * chunk-major persistent schedule: a workgroup owns one (8-channel chunk, 64 output channels) unit and walks a contiguous range of
+//     4 x 32 pixel tiles with the unit's 64 x 96 accumulator block in registers (96 per wave, a wave's own row of pixels as K);
+//     deterministic partials at the end (rvsr_reduce_partials_kernel as before);
+//   * FOUR waves per workgroup, two workgroups per CU: a tile's loads are requested after its predecessor's last LDS read and waited for
+//     at the top of the next tile -- the other workgroup of the CU computes meanwhile (no second set of staging registers: the kernel
+//     sits at the 256-register budget of two waves per SIMD with its accumulators alone taking 96).
+struct DcnBwdW6Params {
+    DcnGeom d;
+    TView g;            // grad_output view (Co, Ho, Wo), plain, optional fused act'
+    float* part;        // [ns][Co][C * 9] weight-gradient partials
+    float* bpart;       // [ns][Co] bias-gradient partials (nullptr: not wanted)
+    int ns;             // tile streams (= partials)
+    int nty;            // tile rows of 4 output rows
+    int ntiles;         // B * nty * ntx
+    int nmb;            // units of 64 output channels
+    int xcd_map;        // 1: units of a stream on one XCD (64 % (nchunks * nmb) == 0)
+};
+
+template <int R, int TERMS>
+__global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params p) {
+    constexpr int NK = 4, TH = 4, NT = TH * 64;
+    constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
+    constexpr int NXI = (2 * NPOS + NT - 1) / NT;                  // x-tile items (float4 of one position and quad) per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* xt = reinterpret_cast<float4*>(smem_raw);              // [2 quads][NPOS], zero outside the image
+    bf16x8* agt = reinterpret_cast<bf16x8*>(xt + 2 * NPOS);        // [4 waves][8 vectors][64 lanes]: the wave's transposed gOut operands (kept out of
+                                                                   // the register file: the kernel sits at the 256-register budget)
+    const DcnGeom& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int nchunks = d.C >> 3, U = nchunks * p.nmb;
+    // workgroup -> (tile stream, unit).  (Integer divisions run on the vector ALU; readfirstlane brings the uniform results back to SGPRs --
+    // left in VGPRs they make every buffer descriptor "divergent": a waterfall loop around each buffer instruction.)
+    const int L = blockIdx.x;
+    const int unit = __builtin_amdgcn_readfirstlane(p.xcd_map ? (L >> 3) % U : L % U);
+    const int stream = __builtin_amdgcn_readfirstlane(p.xcd_map ? (L & 7) + 8 * ((L >> 3) / U) : L / U);
+    if (stream >= p.ns) return;   // (uniform)
+    const int chunk = __builtin_amdgcn_readfirstlane(unit % nchunks), mbw = __builtin_amdgcn_readfirstlane(unit / nchunks);
+    const int c0 = chunk * 8, g = c0 / d.cpg, o0 = 64 * mbw;
+    const int t_begin = __builtin_amdgcn_readfirstlane((int)((long long)p.ntiles * stream / p.ns));
+    const int t_end = __builtin_amdgcn_readfirstlane((int)((long long)p.ntiles * (stream + 1) / p.ns));
+    const int per_b = p.nty * d.ntx;
+    const unsigned HW = (unsigned)(d.H * d.W);
+    const unsigned hw = (unsigned)(d.Ho * d.Wo);
+    const unsigned pl4 = 4u * hw, HW4 = 4u * HW;
+    const bool has_act = p.g.act != nullptr;
+
+    // 0/1 selectors of the transposing MFMAs as B operands: lane (j = lo, h = hi) supplies B[k = 8 h + e][j], e < 8
+    //   even: B[k][j] = (j == k), j < 16        odd: B[k][j] = (j == k + 16)
+    bf16x8 sel_e, sel_o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sel_e[e] = (__bf16)((lo == 8 * hi + e) ? 1.f : 0.f);
+        sel_o[e] = (__bf16)((lo == 8 * hi + e + 16) ? 1.f : 0.f);
+    }
+    f32x16 gw_acc[2][3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) gw_acc[mb][nb] = zero16();
+
+    float o_dy[5], o_dx[5], o_m[5];
+    float xv[NXI][4];
+    auto tile_coords = [&](int t, int& b, int& y0, int& x0) {
+        b = __builtin_amdgcn_readfirstlane(t / per_b);
+        const int rem = t - b * per_b, ty = __builtin_amdgcn_readfirstlane(rem / d.ntx);
+        y0 = ty * TH;
+        x0 = (rem - ty * d.ntx) * 32;
+    };
+    // requests that cross the tile boundary: the (dy, dx, mask) triples of this lane's five taps and the x tile (39 registers; gOut is
+    // fetched at the top of its tile, 32 output channels at a time -- the other workgroup of the CU covers the round trips)
+    auto request = [&](int t) {
+        int b, y0, x0;
+        tile_coords(t, b, y0, x0);
+        const int oy = y0 + wave, ox = x0 + lo;
+        const bool px_ok = oy < d.Ho && ox < d.Wo;
+        {
+            const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs), msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
+            const unsigned ob = (unsigned)(g * 18) * pl4, mb_ = (unsigned)(g * 9) * pl4;
+            const unsigned pv = 4u * (unsigned)(px_ok ? oy * d.Wo + ox : y0 * d.Wo + x0);   // (lanes without a pixel read the tile's first pixel: masked below)
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
+                const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
+                o_dy[it] = buf_load(off_rs, pv + 2u * tp, ob);
+                o_dx[it] = buf_load(off_rs, pv + 2u * tp, ob + pl4);
+                o_m[it] = buf_load(msk_rs, pv + tp, mb_);
             }
         }
-        // (the barrier after the next commit orders this flush before the next tile's atomics)
+        {
+            const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(d.x + (size_t)b * d.C * HW);
+            const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
+#pragma unroll
+            for (int k = 0; k < NXI; ++k) {   // item = (quad, row, col), recomputed per tile (division by a constant: a handful of instructions)
+                const int it = tid + k * NT;
+                const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
+                const int rr_ = pos / TC;
+                const int gy = ty0 + rr_, gx = tx0 + (pos - rr_ * TC);
+                const bool ok = it < 2 * NPOS && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+                const unsigned xo = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * quad) * HW) : 0x80000000u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xo, (unsigned)(c0 + e) * HW4);
+            }
+        }
+    };
+    if (t_begin < t_end) request(t_begin);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        int b, y0, x0;
+        tile_coords(t, b, y0, x0);
+        const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
+        const int oy = y0 + wave, ox = x0 + lo;
+        const bool px_ok = oy < d.Ho && ox < d.Wo;
+        const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
+        // ---- gOut (x act') of this lane's pixel -> bf16 hi / lo fragments -> transposed by the matrix core: G[i = pixel][j = o] lands as
+        // (lane = o, register = pixel) = the A operands of the weight-gradient GEMM: ag[mb][ks][hi, lo].  o = o0 + 16 ks + 8 hi + j; whole
+        // k-steps beyond Co read as zero (Co % 16 == 0): lane offset beyond the 2 GB view
+        bf16x8* my_ag = agt + (wave * 8) * 64 + lane;   // vector (mb, ks, part) at [(mb * 4 + ks * 2 + part) * 64]
+        {
+            const __amdgpu_buffer_rsrc_t g_rs = buf_view_2g(p.g.p + ((size_t)b * d.Co + o0) * hw);
+            const __amdgpu_buffer_rsrc_t a_rs = buf_view_2g((has_act ? p.g.act : p.g.p) + ((size_t)b * d.Co + o0) * hw);
+            const unsigned vo = px_ok ? 4u * (unsigned)(oy * d.Wo + ox) + (unsigned)(8 * hi) * pl4 : 0x80000000u;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float graw[16], araw[16];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int ks = 2 * mb + kk;
+                    const unsigned vk = o0 + 16 * ks < d.Co ? vo : 0x80000000u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        graw[8 * kk + j] = buf_load(g_rs, vk, (unsigned)(16 * ks + j) * pl4);
+                        if (has_act) araw[8 * kk + j] = buf_load(a_rs, vk, (unsigned)(16 * ks + j) * pl4);
+                    }
+                }
+                bf16x8 fh[2], fl[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float f = graw[8 * kk + j];
+                        if (has_act) f *= araw[8 * kk + j] > 0.f ? 1.f : p.g.slope;
+                        v[j] = f;
+                    }
+                    split8(v, fh[kk], fl[kk]);
+                }
+                f32x16 th = mfma_bf16(fh[0], sel_e, zero16());
+                th = mfma_bf16(fh[1], sel_o, th);
+                my_ag[(mb * 4 + 0) * 64] = pack8_exact(th, 0);
+                my_ag[(mb * 4 + 2) * 64] = pack8_exact(th, 8);
+                if (TERMS >= 3) {
+                    f32x16 tl = mfma_bf16(fl[0], sel_e, zero16());
+                    tl = mfma_bf16(fl[1], sel_o, tl);
+                    my_ag[(mb * 4 + 1) * 64] = pack8_exact(tl, 0);
+                    my_ag[(mb * 4 + 3) * 64] = pack8_exact(tl, 8);
+                }
+            }
+        }
+        // ---- commit the x tile
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int it = tid + k * NT;
+            if (it < 2 * NPOS) xt[it] = make_float4(xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
+        }
+        __syncthreads();
+
+        f32x16 dt_h, dt_l;   // column values of two lane iterations, transposed: D[i = pixel][j = 16 (it & 1) + 8 h + ch]
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
+            const bool has_tap = it < 4 || hi == 0;
+            const bool act_lane = px_ok && has_tap;
+            const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
+            float m = o_m[it];
+            if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
+            const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
+            // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616)
+            const float y = (by + kyf) + dy, x = (bx + kxf) + dx;
+            const float fy = floorf(y), fx = floorf(x);
+            const int yi = (int)fy, xi = (int)fx;
+            const float ly = y - fy, lx = x - fx;
+            const int r0 = yi - ty0, s0 = xi - tx0;
+            const bool in_tile = act_lane && (unsigned)r0 < (unsigned)(TR - 1) && (unsigned)s0 < (unsigned)(TC - 1);
+            const bool inside = y > -1.f && x > -1.f && y < (float)d.H && x < (float)d.W;
+            const bool far = !in_tile && inside && act_lane;   // beyond the tile: global gather with the reference's rule set
+            const int pos0 = in_tile ? r0 * TC + s0 : 0;
+            const float ml = in_tile ? m : 0.f;               // dead and far lanes: zero column values on the main path
+            // mask folded into the corner weights (the x tile is zero outside the image: no validity rules inside the tile)
+            const float wy1 = ly * ml, wy0 = ml - wy1;
+            const float w01 = wy0 * lx, w00 = wy0 - w01, w11 = wy1 * lx, w10 = wy1 - w11;
+            const f32x2 W01 = {w00, w01}, W23 = {w10, w11};
+            float colv[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4* xq = xt + q * NPOS + pos0;
+                const float4 a00 = xq[0], a01 = xq[1], a10 = xq[TC], a11 = xq[TC + 1];
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const f32x2 c00 = ph ? f32x2{a00.z, a00.w} : f32x2{a00.x, a00.y};
+                    const f32x2 c01 = ph ? f32x2{a01.z, a01.w} : f32x2{a01.x, a01.y};
+                    const f32x2 c10 = ph ? f32x2{a10.z, a10.w} : f32x2{a10.x, a10.y};
+                    const f32x2 c11 = ph ? f32x2{a11.z, a11.w} : f32x2{a11.x, a11.y};
+                    f32x2 r = pk_mul_x(W01, c00);
+                    r = pk_fma_y(W01, c01, r);
+                    r = pk_fma_x(W23, c10, r);
+                    r = pk_fma_y(W23, c11, r);
+                    colv[4 * q + 2 * ph] = r.x;
+                    colv[4 * q + 2 * ph + 1] = r.y;
+                }
+            }
+            if (far) {   // ---- rare
+                const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
+                const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1, cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
+                const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float u00 = (vy0 && vx0) ? hy * hx * m : 0.f, u01 = (vy0 && vx1) ? hy * lx * m : 0.f;
+                const float u10 = (vy1 && vx0) ? ly * hx * m : 0.f, u11 = (vy1 && vx1) ? ly * lx * m : 0.f;
+                const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e) {
+                    const float* qp = pl + (size_t)e * HW;
+                    const float vq = u00 * qp[i00] + u01 * qp[i01] + u10 * qp[i10] + u11 * qp[i11];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) colv[j] = e == j ? vq : colv[j];
+                }
+            }
+            // (spare slot of iteration 4, half 1: the ones column of the bias gradient)
+            if (it == 4) colv[0] = hi ? (px_ok ? 1.f : 0.f) : colv[0];
+            bf16x8 ch_, cl_;
+            split8(colv, ch_, cl_);
+            if ((it & 1) == 0) {
+                dt_h = mfma_bf16(ch_, sel_e, zero16());
+                if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_e, zero16());
+            } else {
+                dt_h = mfma_bf16(ch_, sel_o, dt_h);
+                if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_o, dt_l);
+            }
+            if ((it & 1) || it == 4) {   // ---- n-block nb = it / 2 complete: gw_acc[mb][nb] += gOut^T[mb] x col, K = this row's 32 pixels
+                const int nb = it >> 1;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 bh = pack8_exact(dt_h, 8 * ks);
+                    bf16x8 bl = bh;
+                    if (TERMS >= 2) bl = pack8_exact(dt_l, 8 * ks);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const bf16x8 ah = my_ag[(mb * 4 + ks * 2) * 64];
+                        gw_acc[mb][nb] = mfma_bf16(ah, bh, gw_acc[mb][nb]);
+                        if (TERMS >= 2) gw_acc[mb][nb] = mfma_bf16(ah, bl, gw_acc[mb][nb]);
+                        if (TERMS >= 3) gw_acc[mb][nb] = mfma_bf16(my_ag[(mb * 4 + ks * 2 + 1) * 64], bh, gw_acc[mb][nb]);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // (every wave is done with the x tile)
+        if (t + 1 < t_end) request(t + 1);
     }
 
-    // ---- weight / bias gradient partial of this (stream, chunk): sum of the 4 waves (8 rows), fixed order, through LDS
+    // ---- partial of this (stream, unit): sum of the 4 waves (rows), fixed order, through LDS
     __syncthreads();
     {
         float* red = reinterpret_cast<float*>(smem_raw);   // [4 waves][16 registers][64 lanes] = 16 KB
@@ -550,12 +814,12 @@ __global__ __launch_bounds__(NW * 64) void dcn_bwd6_kernel(const DcnBwd6Params p
                 for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = gw_acc[mb][nb][r];
                 __syncthreads();
 #pragma unroll
-                for (int rq = 0; rq < 16 / NW; ++rq) {
-                    const int r = wave + NW * rq;     // thread (wave, lane) sums register r of lane `lane` over the waves
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int r = wave + 4 * rq;     // thread (wave, lane) sums register r of lane `lane` over the waves
                     float sum = 0.f;
 #pragma unroll
-                    for (int w4 = 0; w4 < NW; ++w4) sum += red[(w4 * 16 + r) * 64 + lane];
-                    const int o = 32 * mb + drow(r, hi);
+                    for (int w4 = 0; w4 < 4; ++w4) sum += red[(w4 * 16 + r) * 64 + lane];
+                    const int o = o0 + 32 * mb + drow(r, hi);
                     const int it = 2 * nb + (lo >> 4), h2 = (lo >> 3) & 1, ch = lo & 7;
                     const int tap = bwd6_tap(it, h2);
                     if (o < d.Co) {
@@ -569,77 +833,45 @@ __global__ __launch_bounds__(NW * 64) void dcn_bwd6_kernel(const DcnBwd6Params p
     }
 }
 
-size_t rvsr_dcn_bwd6_workspace_bytes(int Co, int C, int* ns_out) {
-    const int nchunks = C / 8;
-    const int ns = nchunks > 0 && 32 % nchunks == 0 ? 256 / nchunks : 0;
-    if (ns_out) *ns_out = ns;
-    const size_t wbytes = (size_t)nchunks * 3 * 2 * 8 * 32 * 16;
-    const size_t nrm = ((size_t)nchunks * 4 + 255) & ~(size_t)255;
-    return wbytes + nrm + (size_t)ns * ((size_t)Co * C * 9 + Co) * sizeof(float) + 256;
+// streams (= partials) of a launch; 0: geometry not covered
+static int bwdw6_streams(int Co, int C, int* nmb_out, int* xcd_out) {
+    const int nchunks = C / 8, nmb = (Co + 63) / 64, U = nchunks * nmb;
+    if (U <= 0 || U > 512) return 0;
+    if (nmb_out) *nmb_out = nmb;
+    if (xcd_out) *xcd_out = 64 % U == 0 ? 1 : 0;
+    return 512 / U;
+}
+size_t rvsr_dcn_bwdw6_workspace_bytes(int Co, int C) {
+    const int ns = bwdw6_streams(Co, C, nullptr, nullptr);
+    return (size_t)ns * ((size_t)Co * C * 9 + Co) * sizeof(float) + 256;
 }
 
-// (dcn5_kernels.hip)
-__global__ void dcn_bwd5_wnorm_kernel(const float* __restrict__ w, float* __restrict__ wn, int Co, int C);
-
-int rvsr_dcn_bwd6_supported(const DcnGeom& d, const TView& g) {
-    if (d.cpg != 8 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 64 || d.Co % 16 != 0 || g.mode != 0) return 0;
-    const int nchunks = d.C / 8;
-    if (nchunks > 32 || 32 % nchunks != 0) return 0;
+// gw / gb are ACCUMULATED into (the reference's convention, cpp:659-671).  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdw4.
+int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const TView& g, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co % 16 != 0 || g.mode != 0) return RVSR_ERR_UNSUPPORTED;
+    int nmb = 0, xcd = 0;
+    const int ns = bwdw6_streams(d.Co, d.C, &nmb, &xcd);
+    if (ns <= 0 || !workspace || workspace_bytes < rvsr_dcn_bwdw6_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
+    // 32-bit byte offsets into one batch element's planes
     const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)d.C ? (size_t)(d.C / d.cpg) * 18 : (size_t)d.C;
-    if (planes * (size_t)d.H * d.W * sizeof(float) >= ((size_t)1 << 31) || planes * (size_t)d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
-        return 0;
-    if ((size_t)d.Co * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31)) return 0;
-    return 1;
-}
-
-template <int R>
-static int launch_bwd6(const DcnBwd6Params& p, const bf16x8* wpack, hipStream_t st) {
-    constexpr int TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
-    const size_t lds = (size_t)NPOS * (2 * 16 + 8 * 4) + (size_t)3 * 2 * 8 * 32 * 16 + 8 * sizeof(float);
-    static const int nw = [] { const char* e = getenv("RVSR_DCN6_NW"); return e ? atoi(e) : 8; }();   // developer A/B switch: waves per workgroup
-    auto k = nw == 4 ? dcn_bwd6_kernel<R, 3, 4> : dcn_bwd6_kernel<R, 3, 8>;
-#ifndef RVSR_DCN6_DEV
-    const int nt = rvsr_gemm_terms();
-    if (nt == 2) k = dcn_bwd6_kernel<R, 2, 8>;
-    if (nt == 1) k = dcn_bwd6_kernel<R, 1, 8>;
-#endif
-    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd6: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(k, dim3(p.ns * (p.d.C / 8)), dim3(nw == 4 ? 256 : 512), lds, st, p, wpack);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd6 launch: %s", hipGetErrorString(e));
-    return RVSR_OK;
-}
-
-// All five gradients of the fused pack / the operator.  gw / gb are ACCUMULATED into (the reference's convention, cpp:659-671).
-// halo: 2 / 4 / 6 (window around the tile); < 0: 4.
-int rvsr_launch_dcn_bwd6(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs, float* gmask,
-                         size_t gmask_bs, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st, int halo) {
-    if (!rvsr_dcn_bwd6_supported(d, g)) return RVSR_ERR_UNSUPPORTED;
-    int ns = 0;
-    if (!workspace || workspace_bytes < rvsr_dcn_bwd6_workspace_bytes(d.Co, d.C, &ns)) return RVSR_ERR_UNSUPPORTED;
-    const int nchunks = d.C / 8;
-    const size_t wbytes = (size_t)nchunks * 3 * 2 * 8 * 32 * 16;
-    bf16x8* wpack = (bf16x8*)workspace;
-    float* wnorm = (float*)((unsigned char*)workspace + wbytes);
-    float* part = (float*)((unsigned char*)workspace + wbytes + (((size_t)nchunks * 4 + 255) & ~(size_t)255));
+    if (planes * (size_t)d.H * d.W * sizeof(float) >= ((size_t)1 << 31) || planes * (size_t)d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31) ||
+        (size_t)64 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
+        return RVSR_ERR_UNSUPPORTED;
+    constexpr int R = 4, TH = 4, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
+    const size_t lds = (size_t)NPOS * 32 + (size_t)4 * 8 * 64 * 16;
+    DcnBwdW6Params p;
+    p.d = d; p.g = g;
     const size_t nw = (size_t)d.Co * d.C * 9;
-    hipLaunchKernelGGL(dcn_bwd5_wnorm_kernel, dim3(nchunks), dim3(576), 0, st, weight, wnorm, d.Co, d.C);
-    const size_t total = (size_t)nchunks * 3 * 8 * 32;
-    hipLaunchKernelGGL(pack_weights_bwd6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, wpack, d.Co, d.C, nchunks);
-    DcnBwd6Params p;
-    p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
-    p.sel = dcn_halo_always(); p.wnorm = wnorm;
-    p.part = part; p.bpart = gb ? part + (size_t)ns * nw : nullptr;
-    p.ns = ns; p.nty = (d.Ho + 7) / 8; p.ntiles = d.B * p.nty * d.ntx;
-    int rc;
-#ifdef RVSR_DCN6_DEV
-    rc = launch_bwd6<4>(p, wpack, st);
-#else
-    if (halo == 2) rc = launch_bwd6<2>(p, wpack, st);
-    else if (halo == 6) rc = launch_bwd6<6>(p, wpack, st);
-    else rc = launch_bwd6<4>(p, wpack, st);
-#endif
-    if (rc != RVSR_OK) return rc;
-    rvsr_launch_reduce(part, ns, nw, gw, 1, st, p.bpart, (size_t)d.Co, gb);
+    p.part = (float*)workspace;
+    p.bpart = gb ? p.part + (size_t)ns * nw : nullptr;
+    p.ns = ns; p.nty = (d.Ho + TH - 1) / TH; p.ntiles = d.B * p.nty * d.ntx; p.nmb = nmb; p.xcd_map = xcd;
+    const int nt = rvsr_gemm_terms();
+    auto k = nt == 2 ? dcn_bwdw6_kernel<R, 2> : (nt == 1 ? dcn_bwdw6_kernel<R, 1> : dcn_bwdw6_kernel<R, 3>);
+    if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdw6: cannot reserve %zu B of LDS", lds);
+    const int U = (d.C / 8) * nmb;
+    hipLaunchKernelGGL(k, dim3(xcd ? 512 : ns * U), dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdw6 launch: %s", hipGetErrorString(e));
+    rvsr_launch_reduce(p.part, ns, nw, gw, 1, st, p.bpart, (size_t)d.Co, gb);
     return RVSR_OK;
 }

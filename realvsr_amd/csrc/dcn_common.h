@@ -131,12 +131,16 @@ int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g
 size_t rvsr_dcn_bwdin_auto_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                                float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);
-// sixth generation (dcn6_kernels.hip): ALL five gradients in one persistent kernel (one sampling pass; 8 channels per deformable group,
-// Co <= 64, stride 1); gw / gb accumulated into.  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdin5 + dcn_bwdw4.
-size_t rvsr_dcn_bwd6_workspace_bytes(int Co, int C, int* ns_out = nullptr);
-int rvsr_dcn_bwd6_supported(const DcnGeom& d, const TView& g);
-int rvsr_launch_dcn_bwd6(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs, float* gmask,
-                         size_t gmask_bs, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1);
+// sixth-generation input / offset / mask gradient (dcn6_kernels.hip): dcn_bwdin5's window with a lane = (pixel, tap) layout and packed math;
+// same calling protocol.  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdin5.
+size_t rvsr_dcn_bwdin6_workspace_bytes(int Co, int C);
+int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
+                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1,
+                           const unsigned* probe_in = nullptr);
+// sixth-generation weight / bias gradient (dcn6_kernels.hip): column values transposed by the matrix core, chunk-major persistent; gw / gb
+// accumulated into.  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdw4.
+size_t rvsr_dcn_bwdw6_workspace_bytes(int Co, int C);
+int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const TView& g, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st);
 // fifth-generation input / offset / mask gradient (dcn5_kernels.hip): shared f64 LDS window; halo < 0 = chosen on the device
 size_t rvsr_dcn_bwdin5_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,

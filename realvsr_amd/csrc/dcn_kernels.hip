@@ -437,8 +437,10 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     size_t b2 = rvsr_dcn_bwdin_auto_workspace_bytes(channels_out, channels);   // both weight images + the probe counter
     const size_t b5 = rvsr_dcn_bwdin5_workspace_bytes(channels_out, channels);
     if (b5 > b2) b2 = b5;
-    const size_t b6 = rvsr_dcn_bwd6_workspace_bytes(channels_out, channels);
+    const size_t b6 = rvsr_dcn_bwdin6_workspace_bytes(channels_out, channels);
     if (b6 > b2) b2 = b6;
+    const size_t w6 = rvsr_dcn_bwdw6_workspace_bytes(channels_out, channels);
+    if (w6 > b2) b2 = w6;
     return a > b2 ? a : b2;
 }
 
@@ -450,22 +452,14 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     TView g;
     g.p = gout; g.act = gact; g.slope = gact_slope; g.C = d.Co; g.Hs = g.Hv = d.Ho; g.Ws = g.Wv = d.Wo; g.mode = 0;
     const int nty = (d.Ho + 3) / 4;
-    if (gx && goff && gmask && gw && rvsr_g_gemm_mode != 1) {
-        // sixth generation: all five gradients from ONE sampling pass (dcn6_kernels.hip) where it covers the call
-        static const int gen6 = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();      // developer A/B switch
-        static const int halo6 = [] { const char* e = getenv("RVSR_DCN6_HALO"); return e ? atoi(e) : -1; }();
-        if (gen6 >= 7) {
-            const int rc6 = rvsr_launch_dcn_bwd6(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, gw, gb, workspace, workspace_bytes, st, halo6);
-            if (rc6 != RVSR_ERR_UNSUPPORTED) return rc6;
-        }
-    }
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
         if (rvsr_g_gemm_mode != 1) {
-            static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 6; }();  // developer A/B switch
+            static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();  // developer A/B switch
             static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
-            if (gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
+            if (gen >= 7) rc2 = rvsr_launch_dcn_bwdin6(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
+            if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 5) rc2 = rvsr_launch_dcn_bwdin_auto(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 3)
                 rc2 = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
@@ -487,6 +481,14 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         } else {
             if (set_lds(dcn_bwd_input_kernel<0>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
             hipLaunchKernelGGL(dcn_bwd_input_kernel<0>, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);
+        }
+    }
+    if (gw && rvsr_g_gemm_mode != 1) {
+        static const int genw = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 6; }();   // developer A/B switch
+        if (genw >= 6) {
+            const int rc6 = rvsr_launch_dcn_bwdw6(d, g, gw, gb, workspace, workspace_bytes, st);
+            if (rc6 == RVSR_OK) gw = nullptr;   // done
+            else if (rc6 != RVSR_ERR_UNSUPPORTED) return rc6;
         }
     }
     if (gw) {
