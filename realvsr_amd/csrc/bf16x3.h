@@ -7,6 +7,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// First MFMA of an accumulator (SrcC = 0).  hipcc selects the untied form, `v_mfma ... vdst, a, b, 0`, and -- when an operand dies at this
+// instruction -- allocates vdst ON TOP of that operand's registers (seen in the listings: `v_mfma_f32_32x32x16_bf16 v[98:113], v[110:113],
+// v[150:153], 0`).  The matrix core reads the k = 8..15 half of the operands passes after the k = 0..7 half and by then may have begun writing
+// vdst: the products of the upper lane half came out wrong, differently from run to run (round 5, profiles/r05_notes.md; tools/
+// check_mfma_overlap.py scans the library for the pattern).  The empty asm keeps `a` and `b` alive across the instruction, so the allocator
+// cannot overlap them with the result; it costs nothing.
+__device__ __forceinline__ f32x16 mfma_bf16_first(bf16x8 a, bf16x8 b) {
+    f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, zero16(), 0, 0, 0);
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+}
 // hi = bf16(v) (round to nearest even), lo = bf16(v - hi).  The exact residual v - hi comes from v_dot2c_f32_bf16 on the PACKED
 // hi pair -- D = v + <(hi0, hi1), (-1, 0)> -- so the pair is never unpacked to f32 again: 4 v_cvt_pk + 8 v_dot2c + 4 v_cvt_pk = 16
 // vector instructions per 8 values, against 24 for the shift / mask / subtract form hipcc makes of `v - (float)hi`.  hi0 * -1 and

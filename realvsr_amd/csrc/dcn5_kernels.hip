@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void dcn_bwdin5_kernel(const DcnBwdIn5Param
             for (int ks = 0; ks < NK; ++ks) {
                 const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo], al = wb_lo[(2 * ks + hi) * 32 + lo];
                 if (RVSR_ABL5 & 16) { acc[0] += (float)ah[0] * (float)gh[ks][0] + (float)al[1] * (float)gl[ks][1]; continue; }
-                acc = mfma_bf16(ah, gh[ks], acc);
+                acc = ks == 0 ? mfma_bf16_first(ah, gh[0]) : mfma_bf16(ah, gh[ks], acc);   // (bf16x3.h: the untied first MFMA must keep its operands)
                 if (TERMS >= 2) acc = mfma_bf16(ah, gl[ks], acc);
                 if (TERMS >= 3) acc = mfma_bf16(al, gh[ks], acc);
             }

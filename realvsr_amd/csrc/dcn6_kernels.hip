@@ -122,7 +122,44 @@ struct DcnBwdIn6Params {
     size_t goff_bs, gmask_bs;
     DcnHaloSel sel;     // kernel selection on the device (dcn_common.h): every candidate halo is launched, one runs
     const float* wnorm; // [chunk]: max over the chunk's 72 (tap, channel) columns of ||W[:, c, tap]||_2  (dcn_bwd5_wnorm_kernel)
+    bf16x8* agt;        // optional side output for dcn_bwdw6 (nullptr: none): gOut x act' of every pixel row as the A operands of the weight-gradient
+    int agt_nmb32;      // GEMM, [b][row][x tile][mb32 (agt_nmb32)][ks (2)][hi, lo][lane (64)] bf16x8 -- see bwd6_emit_agt
+    int agt_rows;       // rows per batch element in that buffer (a multiple of the tile height >= Ho)
 };
+
+// gOut^T by the matrix core.  The fragments gh / gl of a wave hold gOut[o = 16 ks + 8 h + e][pixel = lane & 31] (lane = pixel, K = output channel:
+// the B operand of col_grad = W^T gOut).  The weight gradient gW = gOut col^T needs gOut with PIXELS along K: D = A x [I16 | 0] + A' x [0 | I16] with
+// 0/1 selectors as B operands moves A[i = pixel][k = o] to D[i = pixel][j = o], whose register layout is (lane = j = o, register = i = pixel) --
+// exact (one non-zero product per output, f32 accumulate).  Registers 0..7 / 8..15 of D are the two k-steps of the consumer; the pixel order along
+// K is whatever the D layout makes it, the same for the column operand dcn_bwdw6 builds the same way.
+template <int NK>
+__device__ __forceinline__ void bwd6_emit_agt(bf16x8* dst, int nmb32, const bf16x8 (&gh)[NK], const bf16x8 (&gl)[NK], int lane) {
+    const int lo = lane & 31, hi = lane >> 5;
+    bf16x8 sel_e, sel_o;   // lane (j = lo, h = hi) supplies B[k = 8 h + e][j]:  even: (j == k), j < 16;  odd: (j == k + 16)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sel_e[e] = (__bf16)((lo == 8 * hi + e) ? 1.f : 0.f);
+        sel_o[e] = (__bf16)((lo == 8 * hi + e + 16) ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int m = 0; m < (NK + 1) / 2; ++m) {
+        f32x16 th = mfma_bf16_first(gh[2 * m], sel_e), tl = mfma_bf16_first(gl[2 * m], sel_e);
+        if (2 * m + 1 < NK) {
+            th = mfma_bf16(gh[2 * m + 1], sel_o, th);
+            tl = mfma_bf16(gl[2 * m + 1], sel_o, tl);
+        }
+        bf16x8* q = dst + (size_t)(m * 4) * 64 + lane;
+        q[0 * 64] = pack8_exact(th, 0);
+        q[1 * 64] = pack8_exact(tl, 0);
+        q[2 * 64] = pack8_exact(th, 8);
+        q[3 * 64] = pack8_exact(tl, 8);
+    }
+    const bf16x8 z = {};
+    for (int m = (NK + 1) / 2; m < nmb32; ++m) {   // (Co <= 32 inside a unit of 64 output channels: the second half reads as zero)
+        bf16x8* q = dst + (size_t)(m * 4) * 64 + lane;
+        q[0 * 64] = z; q[1 * 64] = z; q[2 * 64] = z; q[3 * 64] = z;
+    }
+}
 
 // TERMS: terms of the bf16 product W^T * gOut (rvsr_common.h: gemm modes): 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part;
 // 1 = hi*hi.  WPS: workgroups the launch bounds promise per CU.
@@ -200,6 +237,8 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
         if (lane == 0) gn_red[wave] = gsq;
     }
     for (int e = tid; e < 8 * NPOS; e += NT) gwin[e] = 0;
+    if (p.agt != nullptr)   // (uniform) this row's gOut as the weight-gradient kernel wants it (rows beyond Ho: zeros, the buffer covers the tile)
+        bwd6_emit_agt<NK>(p.agt + (((size_t)b * p.agt_rows + oy) * d.ntx + tx) * (size_t)(p.agt_nmb32 * 4 * 64), p.agt_nmb32, gh, gl, lane);
 
     unsigned mg0 = 0x4B400000u;          // 1.5 * 2^23: the magic number of the fixed-point rounding, kept out of the literal encoder
     asm volatile("" : "+s"(mg0));
@@ -266,7 +305,7 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
             for (int ks = 0; ks < NK; ++ks) {
                 const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo];
                 if (RVSR_ABL6 & 8) { acc[ks] += (float)ah[0] * (float)gh[ks][0] + (float)gl[ks][1]; acc[ks + 8] += (float)ah[1]; continue; }
-                acc = mfma_bf16(ah, gh[ks], acc);
+                acc = ks == 0 ? mfma_bf16_first(ah, gh[0]) : mfma_bf16(ah, gh[ks], acc);
                 if (TERMS >= 2) acc = mfma_bf16(ah, gl[ks], acc);
                 if (TERMS >= 3) acc = mfma_bf16(wb_lo[(2 * ks + hi) * 32 + lo], gh[ks], acc);
             }
@@ -348,16 +387,20 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
                     const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
                     float* gp = p.gx + ((size_t)b * d.C + c0) * HW;
                     gm_s = gy_s = gx_s = 0.f;
-#pragma unroll 1
-                    for (int e = 0; e < 8; ++e) {   // (a real loop: unrolled copies of this block in every iteration cost registers on the main path)
+                    // (all 32 loads in flight, no loop over the channels: a rolled `#pragma unroll 1` loop inside this divergent branch made dcn_bwdw6's
+                    // results differ from run to run as soon as two waves shared a SIMD -- hipcc keeps its counter in a VGPR; profiles/r05_notes.md)
+                    float u[8][4];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
                         const float* qp = pl + (size_t)e * HW;
-                        const float c00 = qp[i00] * z00, c01 = qp[i01] * z01, c10 = qp[i10] * z10, c11 = qp[i11] * z11;
+                        u[e][0] = qp[i00]; u[e][1] = qp[i01]; u[e][2] = qp[i10]; u[e][3] = qp[i11];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float c00 = u[e][0] * z00, c01 = u[e][1] * z01, c10 = u[e][2] * z10, c11 = u[e][3] * z11;
                         const float Bq = c01 - c00, Cq = c10 - c00, Dq = (c11 - c01) - Cq;
                         const float dxq = Bq + ly * Dq, dyq = Cq + lx * Dq, vq = (c00 + ly * Cq) + lx * dxq;
-                        float cgq = acc[8 * s];
-#pragma unroll
-                        for (int j = 1; j < 8; ++j) cgq = e == j ? acc[8 * s + j] : cgq;
-                        const float tq = cgq * m;
+                        const float cgq = acc[8 * s + e], tq = cgq * m;
                         gm_s += cgq * vq;
                         gy_s += dyq * tq;
                         gx_s += dxq * tq;
@@ -458,7 +501,7 @@ static int launch_bwdin6_halo(const DcnBwdIn6Params& p, const bf16x8* wpack, int
 // rvsr_launch_dcn_bwdin5, which stays the kernel of geometries this one does not cover (RVSR_ERR_UNSUPPORTED).
 int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo,
-                           const unsigned* probe_in) {
+                           const unsigned* probe_in, void* agt) {
     if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128) return RVSR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < rvsr_dcn_bwdin6_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
     // 32-bit byte offsets into one batch element's planes (x through a 2 GB view: bit 31 marks the zero padding)
@@ -482,6 +525,7 @@ int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g
     DcnBwdIn6Params p;
     p.d = d; p.g = g; p.gx = gx; p.goff = goff; p.gmask = gmask; p.goff_bs = goff_bs; p.gmask_bs = gmask_bs;
     p.sel = dcn_halo_always(); p.wnorm = wnorm;
+    p.agt = (bf16x8*)agt; p.agt_nmb32 = 2 * ((d.Co + 63) / 64); p.agt_rows = ((d.Ho + 7) / 8) * 8;
 #define BWDIN6_DISPATCH(HALO)                                                   \
     switch (NK) {                                                               \
         case 1: rc = launch_bwdin6_halo<1>(p, wpack, HALO, st); break;          \
@@ -549,9 +593,17 @@ int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g
 //   * FOUR waves per workgroup, two workgroups per CU: a tile's loads are requested after its predecessor's last LDS read and waited for
 //     at the top of the next tile -- the other workgroup of the CU computes meanwhile (no second set of staging registers: the kernel
 //     sits at the 256-register budget of two waves per SIMD with its accumulators alone taking 96).
+#ifndef RVSR_ABLW6
+#define RVSR_ABLW6 0   // scratch debug builds of dcn_bwdw6: 1 no far path, 2 barrier per lane iteration, 4 full wait per lane iteration
+#endif
+#if RVSR_ABLW6 & 64   // debug: per-thread checksums of the column values (5 lane iterations) and of the transposed operands (3 n-blocks)
+__device__ float rvsr_dbg_w6[512 * 256 * 8];
+extern "C" int rvsr_debug_read_w6(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_w6), sizeof(float) * 512 * 256 * 8); }
+#endif
 struct DcnBwdW6Params {
     DcnGeom d;
-    TView g;            // grad_output view (Co, Ho, Wo), plain, optional fused act'
+    const bf16x8* agt;  // gOut x act' as A operands, written by dcn_bwdin6 (bwd6_emit_agt): [b][row][x tile][mb32][ks][hi, lo][lane]
+    int agt_nmb32, agt_rows;
     float* part;        // [ns][Co][C * 9] weight-gradient partials
     float* bpart;       // [ns][Co] bias-gradient partials (nullptr: not wanted)
     int ns;             // tile streams (= partials)
@@ -561,14 +613,14 @@ struct DcnBwdW6Params {
     int xcd_map;        // 1: units of a stream on one XCD (64 % (nchunks * nmb) == 0)
 };
 
-template <int R, int TERMS>
-__global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params p) {
-    constexpr int NK = 4, TH = 4, NT = TH * 64;
+template <int R, int TERMS, int TH>
+__global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params p) {
+    constexpr int NK = 4, NT = TH * 64;
     constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
     constexpr int NXI = (2 * NPOS + NT - 1) / NT;                  // x-tile items (float4 of one position and quad) per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);              // [2 quads][NPOS], zero outside the image
-    bf16x8* agt = reinterpret_cast<bf16x8*>(xt + 2 * NPOS);        // [4 waves][8 vectors][64 lanes]: the wave's transposed gOut operands (kept out of
+    bf16x8* agt = reinterpret_cast<bf16x8*>(xt + 2 * NPOS);        // [TH waves][8 vectors][64 lanes]: the wave's transposed gOut operands (kept out of
                                                                    // the register file: the kernel sits at the 256-register budget)
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
@@ -587,7 +639,6 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
     const unsigned HW = (unsigned)(d.H * d.W);
     const unsigned hw = (unsigned)(d.Ho * d.Wo);
     const unsigned pl4 = 4u * hw, HW4 = 4u * HW;
-    const bool has_act = p.g.act != nullptr;
 
     // 0/1 selectors of the transposing MFMAs as B operands: lane (j = lo, h = hi) supplies B[k = 8 h + e][j], e < 8
     //   even: B[k][j] = (j == k), j < 16        odd: B[k][j] = (j == k + 16)
@@ -647,7 +698,27 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
             }
         }
     };
-    if (t_begin < t_end) request(t_begin);
+    // the wave's 8 operand vectors of a tile by LDS-DMA (16 B per lane, no registers): lane l of the wave lands at its slot + 16 l
+    auto fetch_ag = [&](int t) {
+        int b, y0, x0;
+        tile_coords(t, b, y0, x0);
+        const bf16x8* src = p.agt + ((((size_t)b * p.agt_rows + (y0 + wave)) * d.ntx + (x0 >> 5)) * p.agt_nmb32 + 2 * mbw) * (size_t)(4 * 64) + lane;
+        bf16x8* dst = agt + (wave * 8) * 64 + lane;
+        if (RVSR_ABLW6 & 16) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) dst[v * 64] = src[v * 64];
+            return;
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + v * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + v * 64), 16, 0, 0);
+    };
+    float dbg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t_begin < t_end) {
+        request(t_begin);
+        fetch_ag(t_begin);
+    }
 
     for (int t = t_begin; t < t_end; ++t) {
         int b, y0, x0;
@@ -656,51 +727,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
         const int oy = y0 + wave, ox = x0 + lo;
         const bool px_ok = oy < d.Ho && ox < d.Wo;
         const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
-        // ---- gOut (x act') of this lane's pixel -> bf16 hi / lo fragments -> transposed by the matrix core: G[i = pixel][j = o] lands as
-        // (lane = o, register = pixel) = the A operands of the weight-gradient GEMM: ag[mb][ks][hi, lo].  o = o0 + 16 ks + 8 hi + j; whole
-        // k-steps beyond Co read as zero (Co % 16 == 0): lane offset beyond the 2 GB view
-        bf16x8* my_ag = agt + (wave * 8) * 64 + lane;   // vector (mb, ks, part) at [(mb * 4 + ks * 2 + part) * 64]
-        {
-            const __amdgpu_buffer_rsrc_t g_rs = buf_view_2g(p.g.p + ((size_t)b * d.Co + o0) * hw);
-            const __amdgpu_buffer_rsrc_t a_rs = buf_view_2g((has_act ? p.g.act : p.g.p) + ((size_t)b * d.Co + o0) * hw);
-            const unsigned vo = px_ok ? 4u * (unsigned)(oy * d.Wo + ox) + (unsigned)(8 * hi) * pl4 : 0x80000000u;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                float graw[16], araw[16];
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int ks = 2 * mb + kk;
-                    const unsigned vk = o0 + 16 * ks < d.Co ? vo : 0x80000000u;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        graw[8 * kk + j] = buf_load(g_rs, vk, (unsigned)(16 * ks + j) * pl4);
-                        if (has_act) araw[8 * kk + j] = buf_load(a_rs, vk, (unsigned)(16 * ks + j) * pl4);
-                    }
-                }
-                bf16x8 fh[2], fl[2];
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float f = graw[8 * kk + j];
-                        if (has_act) f *= araw[8 * kk + j] > 0.f ? 1.f : p.g.slope;
-                        v[j] = f;
-                    }
-                    split8(v, fh[kk], fl[kk]);
-                }
-                f32x16 th = mfma_bf16(fh[0], sel_e, zero16());
-                th = mfma_bf16(fh[1], sel_o, th);
-                my_ag[(mb * 4 + 0) * 64] = pack8_exact(th, 0);
-                my_ag[(mb * 4 + 2) * 64] = pack8_exact(th, 8);
-                if (TERMS >= 3) {
-                    f32x16 tl = mfma_bf16(fl[0], sel_e, zero16());
-                    tl = mfma_bf16(fl[1], sel_o, tl);
-                    my_ag[(mb * 4 + 1) * 64] = pack8_exact(tl, 0);
-                    my_ag[(mb * 4 + 3) * 64] = pack8_exact(tl, 8);
-                }
-            }
-        }
+        bf16x8* my_ag = agt + (wave * 8) * 64 + lane;   // vector (mb, ks, part) at [(mb * 4 + ks * 2 + part) * 64]; in flight since the end of tile t - 1
         // ---- commit the x tile
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
@@ -715,6 +742,8 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
             const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
             const bool has_tap = it < 4 || hi == 0;
             const bool act_lane = px_ok && has_tap;
+            if (RVSR_ABLW6 & 2) __syncthreads();
+            if (RVSR_ABLW6 & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
             float m = o_m[it];
             if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
@@ -753,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
                     colv[4 * q + 2 * ph + 1] = r.y;
                 }
             }
-            if (far) {   // ---- rare
+            if (far) {   // ---- rare: from global memory with the reference's rule set (kernel.cu:467-497)
                 const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
                 const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1, cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
                 const int i00 = cy0 * d.W + cx0, i01 = cy0 * d.W + cx1, i10 = cy1 * d.W + cx0, i11 = cy1 * d.W + cx1;
@@ -761,27 +790,34 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
                 const float u00 = (vy0 && vx0) ? hy * hx * m : 0.f, u01 = (vy0 && vx1) ? hy * lx * m : 0.f;
                 const float u10 = (vy1 && vx0) ? ly * hx * m : 0.f, u11 = (vy1 && vx1) ? ly * lx * m : 0.f;
                 const float* pl = d.x + ((size_t)b * d.C + c0) * HW;
-#pragma unroll 1
+                float q00[8], q01[8], q10[8], q11[8];   // (all 32 loads in flight; no loop over the channels: see profiles/r05_notes.md)
+#pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float* qp = pl + (size_t)e * HW;
-                    const float vq = u00 * qp[i00] + u01 * qp[i01] + u10 * qp[i10] + u11 * qp[i11];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) colv[j] = e == j ? vq : colv[j];
+                    q00[e] = qp[i00]; q01[e] = qp[i01]; q10[e] = qp[i10]; q11[e] = qp[i11];
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) colv[e] = u00 * q00[e] + u01 * q01[e] + u10 * q10[e] + u11 * q11[e];
             }
             // (spare slot of iteration 4, half 1: the ones column of the bias gradient)
             if (it == 4) colv[0] = hi ? (px_ok ? 1.f : 0.f) : colv[0];
+            if ((RVSR_ABLW6 & 64) && !(RVSR_ABLW6 & 256)) dbg[it] += ((colv[0] + colv[1]) + (colv[2] + colv[3])) + ((colv[4] + colv[5]) + (colv[6] + colv[7]));
+            if ((RVSR_ABLW6 & 256) && it == 2) { dbg[0] += dy; dbg[1] += dx; dbg[2] += m; dbg[3] += (float)pos0; dbg[4] += ((colv[0] + colv[1]) + (colv[2] + colv[3])) + ((colv[4] + colv[5]) + (colv[6] + colv[7])); dbg[5] += w00; dbg[6] += xt[pos0].x + xt[NPOS + pos0 + TC + 1].w; dbg[7] += in_tile ? 1.f : 0.f; }
             bf16x8 ch_, cl_;
             split8(colv, ch_, cl_);
+            if (RVSR_ABLW6 & 128) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(ch_), "+v"(cl_));
             if ((it & 1) == 0) {
-                dt_h = mfma_bf16(ch_, sel_e, zero16());
-                if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_e, zero16());
+                dt_h = mfma_bf16_first(ch_, sel_e);
+                if (TERMS >= 2) dt_l = mfma_bf16_first(cl_, sel_e);
             } else {
                 dt_h = mfma_bf16(ch_, sel_o, dt_h);
                 if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_o, dt_l);
             }
             if ((it & 1) || it == 4) {   // ---- n-block nb = it / 2 complete: gw_acc[mb][nb] += gOut^T[mb] x col, K = this row's 32 pixels
                 const int nb = it >> 1;
+                if ((RVSR_ABLW6 & 64) && !(RVSR_ABLW6 & 256)) { float a = 0.f; for (int r = 0; r < 16; ++r) a += dt_h[r] + dt_l[r]; dbg[5 + nb] += a; }
+                if (it == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's operand vectors have landed (hipcc does not count LDS-DMA)
+                if (it == 1 && (RVSR_ABLW6 & 8)) __syncthreads();
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 bh = pack8_exact(dt_h, 8 * ks);
@@ -797,14 +833,18 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
                 }
             }
         }
+        if (t + 1 < t_end) fetch_ag(t + 1);   // (the MFMAs above consumed this tile's vectors: the slots are free)
         __syncthreads();   // (every wave is done with the x tile)
         if (t + 1 < t_end) request(t + 1);
     }
 
+#if RVSR_ABLW6 & 64
+    for (int i = 0; i < 8; ++i) rvsr_dbg_w6[((size_t)blockIdx.x * 256 + tid) * 8 + i] = dbg[i];
+#endif
     // ---- partial of this (stream, unit): sum of the 4 waves (rows), fixed order, through LDS
     __syncthreads();
     {
-        float* red = reinterpret_cast<float*>(smem_raw);   // [4 waves][16 registers][64 lanes] = 16 KB
+        float* red = reinterpret_cast<float*>(smem_raw);   // [TH waves][16 registers][64 lanes] = 16 / 32 KB (x tile + operand slots: free now)
         const int K = d.C * 9;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -814,11 +854,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
                 for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = gw_acc[mb][nb][r];
                 __syncthreads();
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int r = wave + 4 * rq;     // thread (wave, lane) sums register r of lane `lane` over the waves
+                for (int rq = 0; rq < 16 / TH; ++rq) {
+                    const int r = wave + TH * rq;     // thread (wave, lane) sums register r of lane `lane` over the waves
                     float sum = 0.f;
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) sum += red[(w4 * 16 + r) * 64 + lane];
+                    for (int w4 = 0; w4 < TH; ++w4) sum += red[(w4 * 16 + r) * 64 + lane];
                     const int o = o0 + 32 * mb + drow(r, hi);
                     const int it = 2 * nb + (lo >> 4), h2 = (lo >> 3) & 1, ch = lo & 7;
                     const int tap = bwd6_tap(it, h2);
@@ -836,19 +876,24 @@ __global__ __launch_bounds__(256, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params 
 // streams (= partials) of a launch; 0: geometry not covered
 static int bwdw6_streams(int Co, int C, int* nmb_out, int* xcd_out) {
     const int nchunks = C / 8, nmb = (Co + 63) / 64, U = nchunks * nmb;
-    if (U <= 0 || U > 512) return 0;
+    if (U <= 0 || U > 256) return 0;
     if (nmb_out) *nmb_out = nmb;
-    if (xcd_out) *xcd_out = 64 % U == 0 ? 1 : 0;
-    return 512 / U;
+    // ONE workgroup of 8 waves per CU (two of 4 waves gave run-to-run different results: profiles/r05_notes.md)
+    if (xcd_out) *xcd_out = 32 % U == 0 ? 1 : 0;
+    return 256 / U > 0 ? 256 / U : 1;
 }
 size_t rvsr_dcn_bwdw6_workspace_bytes(int Co, int C) {
     const int ns = bwdw6_streams(Co, C, nullptr, nullptr);
     return (size_t)ns * ((size_t)Co * C * 9 + Co) * sizeof(float) + 256;
 }
+// the operand buffer dcn_bwdin6 writes for dcn_bwdw6: one 16-byte vector per (row, x tile, 32 output channels, k-step, hi / lo, lane)
+size_t rvsr_dcn_bwd6_agt_bytes(int B, int Co, int Ho, int Wo) {
+    return (size_t)B * (((Ho + 7) / 8) * 8) * ((Wo + 31) / 32) * (size_t)(2 * ((Co + 63) / 64)) * 4 * 64 * 16;
+}
 
 // gw / gb are ACCUMULATED into (the reference's convention, cpp:659-671).  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdw4.
-int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const TView& g, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st) {
-    if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co % 16 != 0 || g.mode != 0) return RVSR_ERR_UNSUPPORTED;
+int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128 || agt == nullptr) return RVSR_ERR_UNSUPPORTED;
     int nmb = 0, xcd = 0;
     const int ns = bwdw6_streams(d.Co, d.C, &nmb, &xcd);
     if (ns <= 0 || !workspace || workspace_bytes < rvsr_dcn_bwdw6_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
@@ -857,19 +902,19 @@ int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const TView& g, float* gw, float* gb
     if (planes * (size_t)d.H * d.W * sizeof(float) >= ((size_t)1 << 31) || planes * (size_t)d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31) ||
         (size_t)64 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
         return RVSR_ERR_UNSUPPORTED;
-    constexpr int R = 4, TH = 4, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
-    const size_t lds = (size_t)NPOS * 32 + (size_t)4 * 8 * 64 * 16;
+    constexpr int R = 4, TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
+    const size_t lds = (size_t)NPOS * 32 + (size_t)TH * 8 * 64 * 16;
     DcnBwdW6Params p;
-    p.d = d; p.g = g;
+    p.d = d; p.agt = (const bf16x8*)agt; p.agt_nmb32 = 2 * nmb; p.agt_rows = ((d.Ho + 7) / 8) * 8;
     const size_t nw = (size_t)d.Co * d.C * 9;
     p.part = (float*)workspace;
     p.bpart = gb ? p.part + (size_t)ns * nw : nullptr;
     p.ns = ns; p.nty = (d.Ho + TH - 1) / TH; p.ntiles = d.B * p.nty * d.ntx; p.nmb = nmb; p.xcd_map = xcd;
     const int nt = rvsr_gemm_terms();
-    auto k = nt == 2 ? dcn_bwdw6_kernel<R, 2> : (nt == 1 ? dcn_bwdw6_kernel<R, 1> : dcn_bwdw6_kernel<R, 3>);
+    auto k = nt == 2 ? dcn_bwdw6_kernel<R, 2, TH> : (nt == 1 ? dcn_bwdw6_kernel<R, 1, TH> : dcn_bwdw6_kernel<R, 3, TH>);
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdw6: cannot reserve %zu B of LDS", lds);
     const int U = (d.C / 8) * nmb;
-    hipLaunchKernelGGL(k, dim3(xcd ? 512 : ns * U), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(k, dim3(ns * U), dim3(TH * 64), lds, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdw6 launch: %s", hipGetErrorString(e));
     rvsr_launch_reduce(p.part, ns, nw, gw, 1, st, p.bpart, (size_t)d.Co, gb);

@@ -136,11 +136,13 @@ int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TVie
 size_t rvsr_dcn_bwdin6_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
                            float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st, int halo = -1,
-                           const unsigned* probe_in = nullptr);
+                           const unsigned* probe_in = nullptr, void* agt = nullptr);
 // sixth-generation weight / bias gradient (dcn6_kernels.hip): column values transposed by the matrix core, chunk-major persistent; gw / gb
 // accumulated into.  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdw4.
+// Its gOut operand comes pre-transposed from dcn_bwdin6 (`agt`, rvsr_dcn_bwd6_agt_bytes): the two run as a pair.
 size_t rvsr_dcn_bwdw6_workspace_bytes(int Co, int C);
-int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const TView& g, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t rvsr_dcn_bwd6_agt_bytes(int B, int Co, int Ho, int Wo);
+int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st);
 // fifth-generation input / offset / mask gradient (dcn5_kernels.hip): shared f64 LDS window; halo < 0 = chosen on the device
 size_t rvsr_dcn_bwdin5_workspace_bytes(int Co, int C);
 int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,

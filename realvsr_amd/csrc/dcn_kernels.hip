@@ -427,8 +427,8 @@ extern "C" size_t rvsr_modulated_deform_conv_forward_workspace_bytes(int channel
     return rvsr_dcn_fwd2_workspace_bytes(channels_out, channels);
 }
 
-extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch, int channels, int height, int width,
-                                                                      int channels_out, int stride, int pad, int dil) {
+// everything but the operand buffer dcn_bwdin6 hands to dcn_bwdw6 (that buffer sits behind it, 256-byte aligned)
+static size_t dcn_backward_workspace_base(int batch, int channels, int height, int width, int channels_out, int stride, int pad, int dil) {
     const int Ho = (height + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * 2 + 1)) / stride + 1;
     const int ntiles = batch * ((Ho + 3) / 4) * ((Wo + 31) / 32);
     const int gy = (channels_out + 63) / 64, gz = (channels + DCN_CC - 1) / DCN_CC;
@@ -441,7 +441,14 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
     if (b6 > b2) b2 = b6;
     const size_t w6 = rvsr_dcn_bwdw6_workspace_bytes(channels_out, channels);
     if (w6 > b2) b2 = w6;
-    return a > b2 ? a : b2;
+    return ((a > b2 ? a : b2) + 255) & ~(size_t)255;
+}
+extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch, int channels, int height, int width,
+                                                                      int channels_out, int stride, int pad, int dil) {
+    const int Ho = (height + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * 2 + 1)) / stride + 1;
+    size_t n = dcn_backward_workspace_base(batch, channels, height, width, channels_out, stride, pad, dil);
+    if (stride == 1 && dil == 1 && channels % 8 == 0 && channels_out <= 128) n += rvsr_dcn_bwd6_agt_bytes(batch, channels_out, Ho, Wo);
+    return n;
 }
 
 static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout, const float* gact, float gact_slope,
@@ -452,13 +459,22 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     TView g;
     g.p = gout; g.act = gact; g.slope = gact_slope; g.C = d.Co; g.Hs = g.Hv = d.Ho; g.Ws = g.Wv = d.Wo; g.mode = 0;
     const int nty = (d.Ho + 3) / 4;
+    // dcn_bwdin6 + dcn_bwdw6 run as a pair: the first leaves gOut (x act') behind as the matrix-core operands of the second
+    static const int genw = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 6; }();   // developer A/B switch
+    void* agt = nullptr;
+    bool agt_written = false;
+    if (gx && gw && rvsr_g_gemm_mode != 1 && genw >= 6 && d.stride == 1 && d.dil == 1 && d.C % 8 == 0 && d.Co <= 128)
+        agt = (unsigned char*)workspace + dcn_backward_workspace_base(d.B, d.C, d.H, d.W, d.Co, d.stride, d.pad, d.dil);
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
         if (rvsr_g_gemm_mode != 1) {
             static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();  // developer A/B switch
             static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
-            if (gen >= 7) rc2 = rvsr_launch_dcn_bwdin6(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
+            if (gen >= 7) {
+                rc2 = rvsr_launch_dcn_bwdin6(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe, agt);
+                agt_written = rc2 == RVSR_OK && agt != nullptr;
+            }
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 5) rc2 = rvsr_launch_dcn_bwdin_auto(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 3)
@@ -483,13 +499,10 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
             hipLaunchKernelGGL(dcn_bwd_input_kernel<0>, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);
         }
     }
-    if (gw && rvsr_g_gemm_mode != 1) {
-        static const int genw = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 6; }();   // developer A/B switch
-        if (genw >= 6) {
-            const int rc6 = rvsr_launch_dcn_bwdw6(d, g, gw, gb, workspace, workspace_bytes, st);
-            if (rc6 == RVSR_OK) gw = nullptr;   // done
-            else if (rc6 != RVSR_ERR_UNSUPPORTED) return rc6;
-        }
+    if (gw && agt_written) {
+        const int rc6 = rvsr_launch_dcn_bwdw6(d, agt, gw, gb, workspace, workspace_bytes, st);
+        if (rc6 == RVSR_OK) gw = nullptr;   // done
+        else if (rc6 != RVSR_ERR_UNSUPPORTED) return rc6;
     }
     if (gw) {
         DcnBwdWParams p;

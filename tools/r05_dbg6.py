@@ -33,12 +33,18 @@ def run(B, C, Co, dg, H, W, ostd, seed=0):
     print('gmask per plane (group 0):', ['%.1e' % ((a[:, c] - r[:, c]).abs().max() / r.abs().max()).item() for c in range(9)])
     a, r = got[4], ref[4]
     print('gw per tap:', ['%.1e' % ((a[:, :, k // 3, k % 3] - r[:, :, k // 3, k % 3]).abs().max() / r.abs().max()).item() for k in range(9)])
-    print('gw per channel:', ['%.1e' % ((a[:, c] - r[:, c]).abs().max() / r.abs().max()).item() for c in range(min(C, 16))])
+    print('gw per channel:', ['%.0e' % ((a[:, c] - r[:, c]).abs().max() / r.abs().max()).item() for c in range(C)])
     print('gw per o (first 8, 32..39):', ['%.1e' % ((a[o] - r[o]).abs().max() / r.abs().max()).item() for o in list(range(8)) + list(range(32, 40))])
     a, r = got[1], ref[1]
     e = (a - r).abs().amax(dim=(0, 1))
     print('gx err rows:', ['%.0e' % v for v in e.amax(dim=1).tolist()])
 
-run(1, 64, 64, 8, 8, 32, 0.0)
-run(1, 64, 64, 8, 8, 32, 0.3)
-run(2, 64, 64, 8, 20, 36, 2.0)
+import sys
+if len(sys.argv) > 1:
+    for spec in sys.argv[1:]:
+        a = spec.split(',')
+        run(*[int(v) for v in a[:6]], float(a[6]))
+else:
+    run(1, 64, 64, 8, 8, 32, 0.0)
+    run(1, 64, 64, 8, 8, 32, 0.3)
+    run(2, 64, 64, 8, 20, 36, 2.0)
