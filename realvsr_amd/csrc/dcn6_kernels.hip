@@ -584,22 +584,19 @@ int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g
 //   * the GEMM needs PIXELS along the MFMA's K (register) dimension for both operands, the sampling produces them along the LANE
 //     dimension: the matrix core transposes.  D = A x [I16 | 0] (+ A' x [0 | I16]) with a 0/1 selector as B operand moves
 //     A[i = pixel][k = column] into D[i = pixel][j = column], whose register layout is (lane = j, register = i) -- exact (one non-zero
-//     product per output, f32 accumulate), no LDS tile, no 2-byte stores.  The same two instructions turn the gOut fragments
-//     (lane = pixel, K = output channel) into the A operand (lane = output channel, K = pixel).  The pixel order along K is whatever the
-//     D layout makes it -- the same for both operands, which is all a dot product needs;
+//     product per output, f32 accumulate), no LDS tile, no 2-byte stores.  The pixel order along K is whatever the D layout makes it -- the
+//     same for both operands, which is all a dot product needs;
+//   * the other operand, gOut (x act') with pixels along K, comes pre-transposed from dcn_bwdin6 (bwd6_emit_agt: the same two instructions
+//     on the gOut fragments that kernel holds anyway; one 16-byte vector per (row, x tile, 32 output channels, k-step, hi / lo, lane) in the
+//     backward's workspace).  The two kernels run as a pair; a call that wants the weight gradient alone takes dcn_bwdw4.  The vectors of the
+//     NEXT tile travel by LDS-DMA (no registers) into the wave's own slots as soon as its last MFMA of this tile has read them;
 //   * chunk-major persistent schedule: a workgroup owns one (8-channel chunk, 64 output channels) unit and walks a contiguous range of
-//     4 x 32 pixel tiles with the unit's 64 x 96 accumulator block in registers (96 per wave, a wave's own row of pixels as K);
-//     deterministic partials at the end (rvsr_reduce_partials_kernel as before);
-//   * FOUR waves per workgroup, two workgroups per CU: a tile's loads are requested after its predecessor's last LDS read and waited for
-//     at the top of the next tile -- the other workgroup of the CU computes meanwhile (no second set of staging registers: the kernel
-//     sits at the 256-register budget of two waves per SIMD with its accumulators alone taking 96).
-#ifndef RVSR_ABLW6
-#define RVSR_ABLW6 0   // scratch debug builds of dcn_bwdw6: 1 no far path, 2 barrier per lane iteration, 4 full wait per lane iteration
-#endif
-#if RVSR_ABLW6 & 64   // debug: per-thread checksums of the column values (5 lane iterations) and of the transposed operands (3 n-blocks)
-__device__ float rvsr_dbg_w6[512 * 256 * 8];
-extern "C" int rvsr_debug_read_w6(float* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_w6), sizeof(float) * 512 * 256 * 8); }
-#endif
+//     8 x 32 pixel tiles with the unit's 64 x 96 accumulator block in registers (96 per wave, a wave's own row of pixels as K); the units of a
+//     tile stream sit on one XCD (they read the same operand vectors); deterministic partials at the end (rvsr_reduce_partials_kernel);
+//   * ONE workgroup of 8 waves per CU.  Measured per L1 launch (B = 40, 64 -> 64 channels, 180 x 320): 1.90 ms against dcn_bwdw4's 2.80.
+// Three things this kernel taught (profiles/r05_notes.md): the untied first MFMA of an accumulator must keep its operands alive
+// (bf16x3.h: mfma_bf16_first); no rolled loop inside a divergent branch (the far path is unrolled: 32 loads in flight); two workgroups of four
+// waves per CU gave run-to-run different weight gradients for a reason that was not found -- one workgroup per CU does not.
 struct DcnBwdW6Params {
     DcnGeom d;
     const bf16x8* agt;  // gOut x act' as A operands, written by dcn_bwdin6 (bwd6_emit_agt): [b][row][x tile][mb32][ks][hi, lo][lane]
@@ -607,15 +604,15 @@ struct DcnBwdW6Params {
     float* part;        // [ns][Co][C * 9] weight-gradient partials
     float* bpart;       // [ns][Co] bias-gradient partials (nullptr: not wanted)
     int ns;             // tile streams (= partials)
-    int nty;            // tile rows of 4 output rows
+    int nty;            // tile rows of 8 output rows
     int ntiles;         // B * nty * ntx
     int nmb;            // units of 64 output channels
-    int xcd_map;        // 1: units of a stream on one XCD (64 % (nchunks * nmb) == 0)
+    int xcd_map;        // 1: units of a stream on one XCD (32 % (nchunks * nmb) == 0)
 };
 
 template <int R, int TERMS, int TH>
 __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Params p) {
-    constexpr int NK = 4, NT = TH * 64;
+    constexpr int NT = TH * 64;
     constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
     constexpr int NXI = (2 * NPOS + NT - 1) / NT;                  // x-tile items (float4 of one position and quad) per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -662,8 +659,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         y0 = ty * TH;
         x0 = (rem - ty * d.ntx) * 32;
     };
-    // requests that cross the tile boundary: the (dy, dx, mask) triples of this lane's five taps and the x tile (39 registers; gOut is
-    // fetched at the top of its tile, 32 output channels at a time -- the other workgroup of the CU covers the round trips)
+    // requests that cross the tile boundary in registers: the (dy, dx, mask) triples of this lane's five taps and the x tile
     auto request = [&](int t) {
         int b, y0, x0;
         tile_coords(t, b, y0, x0);
@@ -704,17 +700,11 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         tile_coords(t, b, y0, x0);
         const bf16x8* src = p.agt + ((((size_t)b * p.agt_rows + (y0 + wave)) * d.ntx + (x0 >> 5)) * p.agt_nmb32 + 2 * mbw) * (size_t)(4 * 64) + lane;
         bf16x8* dst = agt + (wave * 8) * 64 + lane;
-        if (RVSR_ABLW6 & 16) {
-#pragma unroll
-            for (int v = 0; v < 8; ++v) dst[v * 64] = src[v * 64];
-            return;
-        }
 #pragma unroll
         for (int v = 0; v < 8; ++v)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + v * 64),
                                              (__attribute__((address_space(3))) void*)(dst + v * 64), 16, 0, 0);
     };
-    float dbg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (t_begin < t_end) {
         request(t_begin);
         fetch_ag(t_begin);
@@ -742,8 +732,6 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
             const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
             const bool has_tap = it < 4 || hi == 0;
             const bool act_lane = px_ok && has_tap;
-            if (RVSR_ABLW6 & 2) __syncthreads();
-            if (RVSR_ABLW6 & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
             float m = o_m[it];
             if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
@@ -801,11 +789,8 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
             }
             // (spare slot of iteration 4, half 1: the ones column of the bias gradient)
             if (it == 4) colv[0] = hi ? (px_ok ? 1.f : 0.f) : colv[0];
-            if ((RVSR_ABLW6 & 64) && !(RVSR_ABLW6 & 256)) dbg[it] += ((colv[0] + colv[1]) + (colv[2] + colv[3])) + ((colv[4] + colv[5]) + (colv[6] + colv[7]));
-            if ((RVSR_ABLW6 & 256) && it == 2) { dbg[0] += dy; dbg[1] += dx; dbg[2] += m; dbg[3] += (float)pos0; dbg[4] += ((colv[0] + colv[1]) + (colv[2] + colv[3])) + ((colv[4] + colv[5]) + (colv[6] + colv[7])); dbg[5] += w00; dbg[6] += xt[pos0].x + xt[NPOS + pos0 + TC + 1].w; dbg[7] += in_tile ? 1.f : 0.f; }
             bf16x8 ch_, cl_;
             split8(colv, ch_, cl_);
-            if (RVSR_ABLW6 & 128) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(ch_), "+v"(cl_));
             if ((it & 1) == 0) {
                 dt_h = mfma_bf16_first(ch_, sel_e);
                 if (TERMS >= 2) dt_l = mfma_bf16_first(cl_, sel_e);
@@ -815,9 +800,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
             }
             if ((it & 1) || it == 4) {   // ---- n-block nb = it / 2 complete: gw_acc[mb][nb] += gOut^T[mb] x col, K = this row's 32 pixels
                 const int nb = it >> 1;
-                if ((RVSR_ABLW6 & 64) && !(RVSR_ABLW6 & 256)) { float a = 0.f; for (int r = 0; r < 16; ++r) a += dt_h[r] + dt_l[r]; dbg[5 + nb] += a; }
                 if (it == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's operand vectors have landed (hipcc does not count LDS-DMA)
-                if (it == 1 && (RVSR_ABLW6 & 8)) __syncthreads();
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 bh = pack8_exact(dt_h, 8 * ks);
@@ -838,9 +821,6 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         if (t + 1 < t_end) request(t + 1);
     }
 
-#if RVSR_ABLW6 & 64
-    for (int i = 0; i < 8; ++i) rvsr_dbg_w6[((size_t)blockIdx.x * 256 + tid) * 8 + i] = dbg[i];
-#endif
     // ---- partial of this (stream, unit): sum of the 4 waves (rows), fixed order, through LDS
     __syncthreads();
     {

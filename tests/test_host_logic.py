@@ -312,3 +312,20 @@ def test_every_autograd_function_carries_the_device_guard():
         entered.clear()
         FakeTensor.device = torch.device('cuda', 0)          # already current: no switch
         assert guarded(None, FakeTensor()) == 'ran' and entered == []
+
+
+def test_no_matrix_core_instruction_overwrites_its_own_operand():
+    """hipcc may allocate the destination of an accumulator's FIRST MFMA (SrcC = 0, untied form) on top of an operand that dies at the
+    instruction; on the MI355X the products of the upper operand half then come out wrong, differently from run to run (round 5,
+    profiles/r05_notes.md; bf16x3.h: mfma_bf16_first).  tools/check_mfma_overlap.py compiles a kernel file to gfx950 ISA and looks for
+    the pattern: run here on the two files whose kernels start accumulators that way (no GPU needed; ~1 minute)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not on PATH')
+    csrc = os.path.join(REPO, 'realvsr_amd', 'csrc')
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'check_mfma_overlap.py'), os.path.join(csrc, 'dcn5_kernels.hip'),
+                          os.path.join(csrc, 'dcn6_kernels.hip')], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert '0 overlapping' in out.stdout

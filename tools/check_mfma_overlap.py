@@ -5,7 +5,7 @@ first MFMA of an accumulator takes SrcC = 0 and an operand dies at the instructi
 then come out wrong from run to run (profiles/r05_notes.md).   usage: tools/check_mfma_overlap.py [file.hip ...]"""
 import glob, os, re, subprocess, sys, tempfile
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'realvsr_amd', 'csrc')
-files = sys.argv[1:] or sorted(glob.glob(os.path.join(root, '*.hip')))
+files = [os.path.abspath(f) for f in sys.argv[1:]] or sorted(glob.glob(os.path.join(root, '*.hip')))
 rng = lambda s: (lambda m: (int(m.group(2)), int(m.group(3) or m.group(2))))(re.match(r'([va])\[?(\d+):?(\d+)?\]?', s))
 bad = 0
 for f in files:
