@@ -47,9 +47,16 @@ const char* rvsr_last_error(void);
  * 2 = two terms (the weights -- in a weight gradient: the output gradient -- rounded to bf16, the
  * other operand hi + lo: exactly the result of mode 0 on bf16-rounded weights), 3 = one term (both
  * operands rounded to bf16); accumulation stays f32, ~2^-9 per product.  Modes 2 / 3 act in the
- * kernels that dominate a training step (3x3 stride-1 forward / data gradient / weight gradient
- * with 64-row m-blocks, the fused DCN forward); every other kernel computes three terms in them.
- * Other values select 0.  Process-wide switch. */
+ * kernels that dominate a training step and ONLY there:
+ *   conv_fwd5   3x3 stride-1 forward and data gradient, when C_out > 32 (64-row m-blocks) and
+ *               the input view is one of the vector-staged ones (16-byte aligned, W % 4 == 0);
+ *   conv_wgrad2 3x3 stride-1 weight gradient (W_out % 4 == 0, 16-byte aligned);
+ *   dcn_fwd3    fused DCN forward with C_out in {64, 128} (3x3, C % 8 == 0);
+ *   dcn_bwdin5 / dcn_bwdin6  fused DCN input / offset / mask gradient (3x3, stride 1, C % 8 == 0, C_out <= 128);
+ *   dcn_bwdw4 / dcn_bwdw6    fused DCN weight gradient (same gate; bwdw4 also W_out % 4 == 0).
+ * Every other kernel (1x1 and strided convs, narrow m-blocks such as the 3-channel output conv, scalar-staged views,
+ * the generic DCN path of section 1c) computes three terms in modes 2 / 3, so a network off those shapes gets
+ * mode 0's result and speed.  Other values select 0.  Process-wide switch. */
 void rvsr_set_gemm_mode(int mode);
 int rvsr_get_gemm_mode(void);
 
@@ -159,6 +166,10 @@ int rvsr_dcn_pack_backward(const float* input, const float* weight, const float*
  *   grad_weight / grad_bias are accumulated into, NULL = skip. */
 size_t rvsr_deform_conv_generic_workspace_bytes(int dtype, int channels, int height, int width, int kernel_h, int kernel_w,
                                                 int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w);
+/* what the forward alone needs (one column buffer instead of two + the f16 scatter planes) */
+size_t rvsr_deform_conv_generic_forward_workspace_bytes(int dtype, int channels, int height, int width, int kernel_h, int kernel_w,
+                                                        int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+                                                        int dilation_w);
 int rvsr_deform_conv_generic_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset,
                                      const void* mask, void* output, int batch, int channels, int height, int width,
                                      int channels_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,

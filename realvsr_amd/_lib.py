@@ -26,6 +26,7 @@ SIGNATURES = {
     'rvsr_deform_conv_backward_input': (c_int, [c_fp] * 6 + [c_int] * 16 + [c_fp, c_size, c_fp]),
     'rvsr_deform_conv_backward_parameters': (c_int, [c_fp] * 4 + [c_int] * 15 + [c_float, c_int, c_fp, c_size, c_fp]),
     'rvsr_deform_conv_generic_workspace_bytes': (c_size, [c_int] * 12),
+    'rvsr_deform_conv_generic_forward_workspace_bytes': (c_size, [c_int] * 12),
     'rvsr_deform_conv_generic_forward': (c_int, [c_int] + [c_fp] * 6 + [c_int] * 15 + [c_fp, c_size, c_fp]),
     'rvsr_deform_conv_generic_backward': (c_int, [c_int] + [c_fp] * 10 + [c_int] * 15 + [c_fp, c_size, c_fp]),
     'rvsr_dcn_pack_forward': (c_int, [c_fp] * 5 + [c_int] * 10 + [c_float, c_fp, c_fp, c_size, c_fp]),

@@ -21,7 +21,7 @@ from .dcn import ModulatedDeformConvPack as DCN
 from .. import functional as RF
 
 LRELU = RF.ACT_LRELU
-_USE_SINKS = os.environ.get('RVSR_GRAD_SINKS', '1') != '0'   # developer A/B switch (functional.GradSink)
+_USE_SINKS = True   # shared gradient buffers for fan-out tensors (functional.GradSink)
 
 
 class Predeblur_ResNet_Pyramid(nn.Module):

@@ -456,8 +456,7 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     p.ntx = (Wout + 31) / 32;
     p.nty = (Hout + 3) / 4;
     p.P = wgrad_P(B * p.nty * p.ntx, gy, gz, ksize);
-    static const int ring = [] { const char* e = getenv("RVSR_WGRAD_RING"); return e ? atoi(e) : 0; }();   // developer A/B switch (measured: no gain, profiles/r04_notes.md)
-    p.ring = ring;
+    p.ring = 0;   // (the X-row ring of conv_wgrad2 measured no gain, profiles/r04_notes.md: compiled out, WGRAD2_RING in conv2_kernels.hip)
     const size_t nw = (size_t)Co * Ctot * ksize * ksize;
     p.part = (float*)workspace;
     p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;

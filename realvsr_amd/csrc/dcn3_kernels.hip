@@ -398,9 +398,7 @@ static int launch_dcn_fwd3_halo(const DcnFwdParams& p, const bf16x8* wpack, int 
 
 // `wpack`: the image pack_weights_kernel(mode 0, CCG 1) wrote for (mt, nchunks, nmb) -- built by rvsr_launch_dcn_fwd2's caller.
 // `probe` (nullable): the three device counters of dcn_offset_probe2_kernel for this call's offsets: the halo is then chosen on the device.
-// `wpack4` (nullable): the image of dcn_fwd4_kernel -- that kernel then takes the small-halo case (R = 3 here) whenever it is the one selected.
-int rvsr_launch_dcn_fwd3(const DcnFwdParams& p_in, const void* wpack, int mt, hipStream_t st, const unsigned* probe, size_t nprobe, int halo_hint,
-                         const void* wpack4) {
+int rvsr_launch_dcn_fwd3(const DcnFwdParams& p_in, const void* wpack, int mt, hipStream_t st, const unsigned* probe, size_t nprobe, int halo_hint) {
     DcnFwdParams p = p_in;
     const DcnGeom& d = p.d;
     if (d.cpg % 8 != 0 || d.stride != 1 || d.dil != 1) return RVSR_ERR_UNSUPPORTED;
@@ -414,7 +412,6 @@ int rvsr_launch_dcn_fwd3(const DcnFwdParams& p_in, const void* wpack, int mt, hi
     int rc = RVSR_OK;
 #define FWD3_DISPATCH(HALO)                                                        \
     do {                                                                           \
-        if ((HALO) <= 3 && wpack4 != nullptr) { rc = rvsr_launch_dcn_fwd4(p, wpack4, st); if (rc != RVSR_ERR_UNSUPPORTED) break; } \
         if (mt == 1) rc = launch_dcn_fwd3_halo<1>(p, wp, HALO, st);                \
         else if (mt == 2) rc = launch_dcn_fwd3_halo<2>(p, wp, HALO, st);           \
         else rc = launch_dcn_fwd3_halo<4>(p, wp, HALO, st);                        \

@@ -545,16 +545,14 @@ int rvsr_launch_dcn_bwdin5(const DcnGeom& d, const float* weight, const TView& g
     // A sample beyond the halo costs 16 global gathers + 16 global atomics (~50x an in-tile sample), a larger halo costs
     // staging and flush work in proportion to its cells (585 / 945 / 1377 / 2065): switch up as soon as a few percent of the
     // offset components leave the smaller tile.
-    static const int pct = [] { const char* e = getenv("RVSR_DCN5_PCT"); return e ? atoi(e) : 2; }();   // developer A/B switch
-    const unsigned thr = (unsigned)(nprobe * (size_t)pct / 100) + 1;
+    const unsigned thr = (unsigned)(nprobe * (size_t)2 / 100) + 1;
     const bool has12 = NK <= 4;
     p.sel.probe = cnt;
     p.sel.thr_ge = p.sel.thr_lt = thr;
     // R = 2: few components beyond 2.5 px; R = 4 (round 4: two workgroups per CU like R = 2, where R = 5 fits once): else, few beyond
     // 3.5 px (hence fewer still beyond its 4.5); R = 5: else, few beyond 5.5; R = 8: else, few beyond 8.5 (or no larger tile); R = 12: the
     // rest.  The counters are monotone, so the chain is a partition.
-    static const int use4 = [] { const char* e = getenv("RVSR_DCN5_R4"); return e ? atoi(e) : 1; }();   // developer A/B switch
-    if (has12 && use4) {
+    if (has12) {
         const int halos[5] = {2, 4, 5, 8, 12}, ge[5] = {-1, 0, 1, 2, 4}, lt[5] = {0, 1, 2, 4, -1};
         for (int k = 0; k < 5; ++k) {
             p.sel.ge = ge[k]; p.sel.lt = lt[k];

@@ -109,28 +109,11 @@ int rvsr_launch_dcn_fwd2(const DcnFwdParams& p, void* workspace, size_t workspac
                          size_t nprobe = 0, int halo_hint = 0);
 // third-generation forward (dcn3_kernels.hip): consumes the weight image rvsr_launch_dcn_fwd2 packs; stride 1, dilation 1
 int rvsr_launch_dcn_fwd3(const DcnFwdParams& p, const void* wpack, int mt, hipStream_t st, const unsigned* probe = nullptr, size_t nprobe = 0,
-                         int halo_hint = 0, const void* wpack4 = nullptr);
-// fourth-generation forward (dcn4_kernels.hip): one software pipeline per wave, 5 x 7 px halo; its own weight image ("layout 2",
-// pack_weights_kernel mode 2) which sits BEHIND the third generation's in the workspace / the cached image buffer
-int rvsr_dcn_fwd4_geom(int Co, int C, int& mt, int& nk, int& nmb);
-size_t rvsr_dcn_fwd4_image_bytes(int Co, int C);
-int rvsr_dcn_fwd4_supported(const DcnGeom& d);
-int rvsr_launch_dcn_fwd4(const DcnFwdParams& p, const void* wpack2, hipStream_t st);
+                         int halo_hint = 0);
 // the three-counter offset statistic both DCN directions select their tile halo from (dcn5_kernels.hip); returns the sample count
 size_t rvsr_launch_dcn_offset_probe(const DcnGeom& d, unsigned* cnt, hipStream_t st);
-size_t rvsr_dcn_bwdin2_workspace_bytes(int Co, int C);
-int rvsr_launch_dcn_bwdin2(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
-                           const unsigned* probe = nullptr, unsigned probe_lo = 0, unsigned probe_hi = 0xffffffffu, int halo = 3);
 int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* bpart_or_null, int P, int nty, int gy, int gz,
                           hipStream_t st);
-size_t rvsr_dcn_bwdin3_workspace_bytes(int Co, int C);
-int rvsr_launch_dcn_bwdin3(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                           float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st,
-                           const unsigned* probe = nullptr, unsigned probe_lo = 0, unsigned probe_hi = 0xffffffffu);
-size_t rvsr_dcn_bwdin_auto_workspace_bytes(int Co, int C);
-int rvsr_launch_dcn_bwdin_auto(const DcnGeom& d, const float* weight, const TView& g, float* gx, float* goff, size_t goff_bs,
-                               float* gmask, size_t gmask_bs, void* workspace, size_t workspace_bytes, hipStream_t st);
 // sixth-generation input / offset / mask gradient (dcn6_kernels.hip): dcn_bwdin5's window with a lane = (pixel, tap) layout and packed math;
 // same calling protocol.  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdin5.
 size_t rvsr_dcn_bwdin6_workspace_bytes(int Co, int C);

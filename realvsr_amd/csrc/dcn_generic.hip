@@ -259,6 +259,12 @@ int g_check(const GArgs& a, GGeo& q, const char* who) {
     return RVSR_OK;
 }
 
+// the forward needs one column buffer only
+template <typename T> size_t g_ws_fwd_bytes(const GArgs& a, const GGeo& q) {
+    const size_t n = (size_t)a.C * a.kh * a.kw * q.Ho * q.Wo * sizeof(T);
+    return (n + 255) & ~(size_t)255;
+}
+
 template <typename T> size_t g_ws_bytes(const GArgs& a, const GGeo& q) {
     // two column buffers (columns, column gradients) + the f32 scatter planes of the f16 path
     size_t n = 2 * (size_t)a.C * a.kh * a.kw * q.Ho * q.Wo * sizeof(T);
@@ -272,7 +278,8 @@ int g_forward(const GArgs& a, const T* x, const T* w, const T* bias, const T* of
     GGeo q;
     int rc = g_check(a, q, "deform_conv_generic_forward");
     if (rc) return rc;
-    if (!ws || ws_bytes < g_ws_bytes<T>(a, q)) FAIL(RVSR_ERR_WORKSPACE, "deform_conv_generic_forward: workspace %zu B < %zu B", ws_bytes, g_ws_bytes<T>(a, q));
+    if (!ws || ws_bytes < g_ws_fwd_bytes<T>(a, q))
+        FAIL(RVSR_ERR_WORKSPACE, "deform_conv_generic_forward: workspace %zu B < %zu B", ws_bytes, g_ws_fwd_bytes<T>(a, q));
     const int K = a.kh * a.kw, cg = a.C / a.group, og = a.Co / a.group;
     const size_t HWo = (size_t)q.Ho * q.Wo;
     T* col = (T*)ws;
@@ -351,6 +358,14 @@ extern "C" size_t rvsr_deform_conv_generic_workspace_bytes(int dtype, int channe
     GGeo q;
     if (channels <= 0 || g_check(a, q, "deform_conv_generic_workspace_bytes") != RVSR_OK) return 0;
     return dtype == 1 ? g_ws_bytes<double>(a, q) : (dtype == 2 ? g_ws_bytes<half_t>(a, q) : g_ws_bytes<float>(a, q));
+}
+
+extern "C" size_t rvsr_deform_conv_generic_forward_workspace_bytes(int dtype, int channels, int height, int width, int kernel_h, int kernel_w,
+                                                                   int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h, int dilation_w) {
+    GArgs a = {1, channels, height, width, 1, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, 1, 1};
+    GGeo q;
+    if (channels <= 0 || g_check(a, q, "deform_conv_generic_forward_workspace_bytes") != RVSR_OK) return 0;
+    return dtype == 1 ? g_ws_fwd_bytes<double>(a, q) : (dtype == 2 ? g_ws_fwd_bytes<half_t>(a, q) : g_ws_fwd_bytes<float>(a, q));
 }
 
 extern "C" int rvsr_deform_conv_generic_forward(int dtype, const void* input, const void* weight, const void* bias, const void* offset, const void* mask,

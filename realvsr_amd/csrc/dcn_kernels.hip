@@ -434,9 +434,7 @@ static size_t dcn_backward_workspace_base(int batch, int channels, int height, i
     const int gy = (channels_out + 63) / 64, gz = (channels + DCN_CC - 1) / DCN_CC;
     const size_t Q = 8 * (size_t)bww_P(ntiles, gy, gz);
     const size_t a = sizeof(float) * Q * ((size_t)channels_out * channels * 9 + channels_out);
-    size_t b2 = rvsr_dcn_bwdin_auto_workspace_bytes(channels_out, channels);   // both weight images + the probe counter
-    const size_t b5 = rvsr_dcn_bwdin5_workspace_bytes(channels_out, channels);
-    if (b5 > b2) b2 = b5;
+    size_t b2 = rvsr_dcn_bwdin5_workspace_bytes(channels_out, channels);   // weight image + column norms + the probe counters
     const size_t b6 = rvsr_dcn_bwdin6_workspace_bytes(channels_out, channels);
     if (b6 > b2) b2 = b6;
     const size_t w6 = rvsr_dcn_bwdw6_workspace_bytes(channels_out, channels);
@@ -476,11 +474,6 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
                 agt_written = rc2 == RVSR_OK && agt != nullptr;
             }
             if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 6) rc2 = rvsr_launch_dcn_bwdin5(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe);
-            if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 5) rc2 = rvsr_launch_dcn_bwdin_auto(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
-            if (rc2 == RVSR_ERR_UNSUPPORTED && gen >= 3)
-                rc2 = rvsr_launch_dcn_bwdin3(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
-            if (rc2 == RVSR_ERR_UNSUPPORTED)
-                rc2 = rvsr_launch_dcn_bwdin2(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st);
         }
         if (rc2 != RVSR_ERR_UNSUPPORTED && rc2 != RVSR_OK) return rc2;
         DcnBwdInParams p;
@@ -490,7 +483,7 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
         // (the LDS bound belongs to the first-generation kernel only: checked where that kernel is actually launched)
         if (rc2 != RVSR_OK && lds > 160 * 1024) FAIL(RVSR_ERR_UNSUPPORTED, "dcn backward: channels_out %d needs %zu B of LDS", d.Co, lds);
         if (rc2 == RVSR_OK) {
-            // done by the second-generation kernel
+            // done by dcn_bwdin6 / dcn_bwdin5
         } else if (d.cpg % DCN_CC == 0) {
             if (set_lds(dcn_bwd_input_kernel<8>, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwd_input: cannot reserve %zu B of LDS", lds);
             hipLaunchKernelGGL(dcn_bwd_input_kernel<8>, dim3(d.ntx * nty, 1, d.B), dim3(RVSR_WG), lds, st, p);

@@ -199,15 +199,8 @@ static inline void rvsr_launch_reduce(const float* part, int P, size_t n, float*
 
 #include <stdio.h>
 #include <stdlib.h>
-// developer A/B switch: RVSR_XCD_SWIZZLE=0 disables the XCD-aware workgroup remap
-static inline int rvsr_swizzle_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("RVSR_XCD_SWIZZLE");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
-}
+// (the XCD-aware workgroup remap is always on; it affects speed only)
+static inline int rvsr_swizzle_enabled() { return 1; }
 // one error string per host thread, shared by all translation units (defined in misc_kernels.hip)
 extern thread_local char rvsr_g_err[256];
 #define FAIL(code, ...)                                        \

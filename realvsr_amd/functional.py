@@ -95,8 +95,8 @@ class GradSink:
         return buf
 
 
-_ADOPT_FLAT_GRADS = os.environ.get('RVSR_FLAT_GRAD_ADOPT', '1') != '0'   # developer A/B switch
-_FUSE_GRAD_MASK = os.environ.get('RVSR_FUSE_GRAD_MASK', '1') != '0'     # developer A/B switch (ResBlock backward: relu' in dgrad2's epilogue)
+_ADOPT_FLAT_GRADS = True   # parameter gradients are written in place of the flat buffer (optim.FlatBuffers)
+_FUSE_GRAD_MASK = True     # ResBlock backward: relu' of the hidden activation in the epilogue of conv2's data gradient
 
 
 def _pgrad(p, zero=False):
@@ -123,7 +123,7 @@ def _pgrad(p, zero=False):
 
 
 
-_PACK_VERIFY = os.environ.get('RVSR_PACK_VERIFY', '0') == '1'
+_PACK_VERIFY = False   # debug (set it from a test): on a cache hit, pack the weight again and compare
 
 
 # ------------------------------------------------------------------------------------------ packed weights, once per step
@@ -203,7 +203,7 @@ class PackedWeights:
         L = _lib.lib()
         buf = e[0] if e is not None and e[0].numel() >= nbytes and e[0].device == weight.device else \
             torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=weight.device)
-        desc = (ctypes.c_longlong * 20)()   # (the DCN forward keeps two images in one buffer: second descriptor in desc[10:])
+        desc = (ctypes.c_longlong * 20)()   # (second descriptor, desc[10:]: unused since the fourth-generation DCN forward left the library)
         if kind == 'conv':
             got = L.rvsr_conv2d_pack_weights(_p(weight), C_in, Co, k, w_mode, _p(buf), buf.numel(), desc, _stream())
         else:
@@ -212,17 +212,11 @@ class PackedWeights:
             return None
         self.stats['packs'] += 1
         self.entries[key] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc[:10]), weight.data_ptr()]
-        if kind != 'conv' and desc[11] != 0:
-            # the image of the fourth-generation DCN forward, behind the first one in the same buffer: its own entry so that
-            # repack() refreshes it as well (same tensor object: the cache hit above returns the whole buffer)
-            self.entries[key + ('image2',)] = [buf, weakref.ref(weight), self._version(weight), self.epoch, list(desc[10:20]), weight.data_ptr()]
-        else:
-            self.entries.pop(key + ('image2',), None)
         self.table = None
         return buf
 
     def _verify(self, e, weight, kind, C_in, Co, k, w_mode):
-        """RVSR_PACK_VERIFY=1 (debug): on a cache hit, pack the weight again and compare -- catches writes that bypassed both torch's
+        """functional._PACK_VERIFY = True (debug): on a cache hit, pack the weight again and compare -- catches writes that bypassed both torch's
         version counter and repack()/invalidate() (p.data.copy_, raw writes into FlatBuffers.param, EMA swaps)."""
         L = _lib.lib()
         tmp = torch.empty_like(e[0])
@@ -745,7 +739,7 @@ def _generic_dcn_forward(input, offset, mask, weight, bias, stride, padding, dil
     bias = None if bias is None else bias.contiguous()
     out = input.new_empty(input.shape[0], weight.shape[0], Ho, Wo)
     L = _lib.lib()
-    ws = _workspace(L.rvsr_deform_conv_generic_workspace_bytes(dt, *geo[1:4], *geo[5:]), input.device)
+    ws = _workspace(L.rvsr_deform_conv_generic_forward_workspace_bytes(dt, *geo[1:4], *geo[5:]), input.device)
     _lib.check(L.rvsr_deform_conv_generic_forward(dt, _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(out), *geo, groups, dg,
                                                   _p(ws), ws.numel(), _stream()), 'deform_conv_generic_forward')
     return out

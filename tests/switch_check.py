@@ -33,7 +33,7 @@ def main():
         errs.append(rel_err(out.detach().cpu(), oracle_dcn(*[x.detach() for x in ref], 1, 1, 1, 1, 8)))
         print('dcn', C, Co, H, W, ostd, ' '.join('%.1e' % e for e in errs))
         worst = max(worst, max(errs))
-    # (the 24 x 128 frame takes the 8 x 64 tile of conv_fwd5 unless RVSR_CONV_WIDE=0, the 36 x 72 ones its 16 x 32 tile)
+    # (the 24 x 128 frame takes the 8 x 64 tile of conv_fwd5, the 36 x 72 ones its 16 x 32 tile)
     for k, s, Ci, Co, Hc, Wc in ((3, 1, 64, 64, 36, 72), (3, 1, 64, 64, 24, 128), (3, 1, 128, 216, 36, 72), (1, 1, 64, 64, 36, 72), (3, 2, 64, 64, 36, 72)):
         g = torch.Generator().manual_seed(k * 10 + s)
         conv = torch.nn.Conv2d(Ci, Co, k, s, k // 2)
@@ -56,7 +56,7 @@ def main():
         print('conv', k, s, Ci, Co, Hc, Wc, ' '.join('%.1e' % e for e in errs))
         worst = max(worst, max(errs))
     # residual block (arch_util.ResidualBlock_noBN) as one autograd node: relu' of the hidden activation is applied in the epilogue of
-    # conv2's data gradient on frames the 8 x 64 tile takes (24 x 128), by the consumers otherwise (36 x 72) and under RVSR_FUSE_GRAD_MASK=0
+    # conv2's data gradient on frames the 8 x 64 tile takes (24 x 128), by the consumers otherwise (36 x 72)
     for Hc, Wc in ((24, 128), (36, 72)):
         g = torch.Generator().manual_seed(Hc)
         c1, c2 = torch.nn.Conv2d(64, 64, 3, 1, 1), torch.nn.Conv2d(64, 64, 3, 1, 1)

@@ -1,6 +1,8 @@
-"""Every developer switch that selects an older kernel generation or a fixed variant (realvsr_amd/csrc: RVSR_DCN_FWD, RVSR_DCN_BWD, RVSR_DCN_BWDW, RVSR_DCN3_HALO, RVSR_DCN5_HALO, RVSR_DCN_MT_WIDE, RVSR_CONV_WIDE, RVSR_CONV_FWD6, RVSR_XCD_SWIZZLE; realvsr_amd: RVSR_FLAT_GRAD_ADOPT, RVSR_PACK_CACHE, RVSR_GRAD_SINKS, RVSR_FUSE_GRAD_MASK) still produces reference
-arithmetic: those kernels are also the fallbacks for geometries the newest ones do not cover.  The switches are read once per
-process, so each setting runs tests/switch_check.py in a subprocess.  -m gpu"""
+"""The developer switches that select the previous kernel generation or a fixed window / tile halo (realvsr_amd/csrc: RVSR_DCN_BWD,
+RVSR_DCN_BWDW, RVSR_DCN3_HALO, RVSR_DCN5_HALO; realvsr_amd: RVSR_PACK_CACHE) still produce reference arithmetic: the previous generation is
+also the fallback for calls the newest kernels do not take, and every window size is a kernel of its own that the device-side selection only
+reaches at the matching offset scale.  The switches are read once per process, so each setting runs tests/switch_check.py in a
+subprocess.  (Round 5 moved the older generations out of the library: experiments/.)  -m gpu"""
 import os
 import subprocess
 import sys
@@ -10,15 +12,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-SETTINGS = ['RVSR_DCN_FWD=2', 'RVSR_DCN_BWD=2', 'RVSR_DCN_BWD=3', 'RVSR_DCN_BWD=4',
-            'RVSR_DCN_BWD=5', 'RVSR_DCN5_HALO=2', 'RVSR_DCN5_HALO=5', 'RVSR_DCN5_HALO=8', 'RVSR_DCN5_HALO=12', 'RVSR_DCN_BWDW=3',
-            'RVSR_DCN_BWDW=2', 'RVSR_DCN_MT_WIDE=2', 'RVSR_XCD_SWIZZLE=0', 'RVSR_FLAT_GRAD_ADOPT=0', 'RVSR_DCN3_HALO=3', 'RVSR_DCN3_HALO=7',
-            'RVSR_DCN3_HALO=11', 'RVSR_CONV_WIDE=0', 'RVSR_PACK_CACHE=0', 'RVSR_CONV_FWD6=1', 'RVSR_FUSE_GRAD_MASK=0',
-            # the fourth-generation DCN forward (dcn4_kernels.hip: persistent, software-pipelined; measured, not the default -- see
-            # profiles/r04_notes.md), in its workgroup shapes; the 4 px / 7 px cases of switch_check.py run its fix-up pass
-            'RVSR_DCN_FWD=4',
-            # conv_wgrad2 with the X rows of vertical neighbour tiles kept in LDS (a ring of six row slots): measured, no gain, off by default
-            'RVSR_WGRAD_RING=1', 'RVSR_DCN5_HALO=4', 'RVSR_DCN5_R4=0']
+SETTINGS = ['RVSR_DCN_BWD=6',        # dcn_bwdin5 + dcn_bwdw4 (round 4's pair; dcn_bwdw6 needs dcn_bwdin6's operand buffer)
+            'RVSR_DCN_BWDW=4',       # dcn_bwdin6 + dcn_bwdw4
+            'RVSR_DCN5_HALO=2', 'RVSR_DCN5_HALO=4', 'RVSR_DCN5_HALO=5', 'RVSR_DCN5_HALO=8', 'RVSR_DCN5_HALO=12',          # dcn_bwdin6's windows
+            'RVSR_DCN_BWD=6,RVSR_DCN5_HALO=2', 'RVSR_DCN_BWD=6,RVSR_DCN5_HALO=5', 'RVSR_DCN_BWD=6,RVSR_DCN5_HALO=12',   # dcn_bwdin5's
+            'RVSR_DCN3_HALO=3', 'RVSR_DCN3_HALO=7', 'RVSR_DCN3_HALO=11', 'RVSR_PACK_CACHE=0']
 
 
 @pytest.mark.parametrize('setting', SETTINGS)
