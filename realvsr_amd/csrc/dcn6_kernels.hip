@@ -617,8 +617,9 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
     constexpr int NXI = (2 * NPOS + NT - 1) / NT;                  // x-tile items (float4 of one position and quad) per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);              // [2 quads][NPOS], zero outside the image
-    bf16x8* agt = reinterpret_cast<bf16x8*>(xt + 2 * NPOS);        // [TH waves][8 vectors][64 lanes]: the wave's transposed gOut operands (kept out of
-                                                                   // the register file: the kernel sits at the 256-register budget)
+    bf16x8* agt = reinterpret_cast<bf16x8*>(xt + 2 * NPOS);        // [2][TH waves][8 vectors][64 lanes]: the wave's transposed gOut operands of this
+                                                                   // and the next tile (kept out of the register file: the kernel sits at the
+                                                                   // 256-register budget)
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int nchunks = d.C >> 3, U = nchunks * p.nmb;
@@ -659,55 +660,55 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         y0 = ty * TH;
         x0 = (rem - ty * d.ntx) * 32;
     };
-    // requests that cross the tile boundary in registers: the (dy, dx, mask) triples of this lane's five taps and the x tile
-    auto request = [&](int t) {
-        int b, y0, x0;
-        tile_coords(t, b, y0, x0);
+    // Everything a tile reads from global memory is requested ONE TILE AHEAD (a tile is ~2 us of work for the workgroup, a round trip under
+    // load about as much): the x tile into registers right after the previous one was committed to LDS, the operand vectors by LDS-DMA into
+    // the other slot set, and the (dy, dx, mask) triple of lane iteration `it` into the registers iteration `it` of this tile has just
+    // consumed.  (First version: all requests at the end of the tile, consumed at the top of the next: 1.90 ms per L1 launch.)
+    const unsigned ob = (unsigned)(g * 18) * pl4, mb_ = (unsigned)(g * 9) * pl4;
+    auto request_offsets = [&](int it, const __amdgpu_buffer_rsrc_t& off_rs, const __amdgpu_buffer_rsrc_t& msk_rs, unsigned pv) {
+        const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
+        const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
+        o_dy[it] = buf_load(off_rs, pv + 2u * tp, ob);
+        o_dx[it] = buf_load(off_rs, pv + 2u * tp, ob + pl4);
+        o_m[it] = buf_load(msk_rs, pv + tp, mb_);
+    };
+    auto pixel_offset = [&](int y0, int x0) {   // (lanes without a pixel read the tile's first pixel: masked when used)
         const int oy = y0 + wave, ox = x0 + lo;
-        const bool px_ok = oy < d.Ho && ox < d.Wo;
-        {
-            const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs), msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
-            const unsigned ob = (unsigned)(g * 18) * pl4, mb_ = (unsigned)(g * 9) * pl4;
-            const unsigned pv = 4u * (unsigned)(px_ok ? oy * d.Wo + ox : y0 * d.Wo + x0);   // (lanes without a pixel read the tile's first pixel: masked below)
+        return 4u * (unsigned)((oy < d.Ho && ox < d.Wo) ? oy * d.Wo + ox : y0 * d.Wo + x0);
+    };
+    auto request_x = [&](int b, int y0, int x0) {
+        const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(d.x + (size_t)b * d.C * HW);
+        const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
-                const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
-                o_dy[it] = buf_load(off_rs, pv + 2u * tp, ob);
-                o_dx[it] = buf_load(off_rs, pv + 2u * tp, ob + pl4);
-                o_m[it] = buf_load(msk_rs, pv + tp, mb_);
-            }
-        }
-        {
-            const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(d.x + (size_t)b * d.C * HW);
-            const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
+        for (int k = 0; k < NXI; ++k) {   // item = (quad, row, col), recomputed per tile (division by a constant: a handful of instructions)
+            const int it = tid + k * NT;
+            const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
+            const int rr_ = pos / TC;
+            const int gy = ty0 + rr_, gx = tx0 + (pos - rr_ * TC);
+            const bool ok = it < 2 * NPOS && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            const unsigned xo = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * quad) * HW) : 0x80000000u;
 #pragma unroll
-            for (int k = 0; k < NXI; ++k) {   // item = (quad, row, col), recomputed per tile (division by a constant: a handful of instructions)
-                const int it = tid + k * NT;
-                const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
-                const int rr_ = pos / TC;
-                const int gy = ty0 + rr_, gx = tx0 + (pos - rr_ * TC);
-                const bool ok = it < 2 * NPOS && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-                const unsigned xo = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * quad) * HW) : 0x80000000u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xo, (unsigned)(c0 + e) * HW4);
-            }
+            for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xo, (unsigned)(c0 + e) * HW4);
         }
     };
     // the wave's 8 operand vectors of a tile by LDS-DMA (16 B per lane, no registers): lane l of the wave lands at its slot + 16 l
-    auto fetch_ag = [&](int t) {
-        int b, y0, x0;
-        tile_coords(t, b, y0, x0);
+    auto fetch_ag = [&](int b, int y0, int x0, int set) {
         const bf16x8* src = p.agt + ((((size_t)b * p.agt_rows + (y0 + wave)) * d.ntx + (x0 >> 5)) * p.agt_nmb32 + 2 * mbw) * (size_t)(4 * 64) + lane;
-        bf16x8* dst = agt + (wave * 8) * 64 + lane;
+        bf16x8* dst = agt + ((set * TH + wave) * 8) * 64 + lane;
 #pragma unroll
         for (int v = 0; v < 8; ++v)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + v * 64),
                                              (__attribute__((address_space(3))) void*)(dst + v * 64), 16, 0, 0);
     };
     if (t_begin < t_end) {
-        request(t_begin);
-        fetch_ag(t_begin);
+        int b, y0, x0;
+        tile_coords(t_begin, b, y0, x0);
+        fetch_ag(b, y0, x0, 0);
+        request_x(b, y0, x0);
+        const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs), msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
+        const unsigned pv = pixel_offset(y0, x0);
+#pragma unroll
+        for (int it = 0; it < 5; ++it) request_offsets(it, off_rs, msk_rs, pv);
     }
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -717,14 +718,23 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         const int oy = y0 + wave, ox = x0 + lo;
         const bool px_ok = oy < d.Ho && ox < d.Wo;
         const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
-        bf16x8* my_ag = agt + (wave * 8) * 64 + lane;   // vector (mb, ks, part) at [(mb * 4 + ks * 2 + part) * 64]; in flight since the end of tile t - 1
-        // ---- commit the x tile
+        const int set = (t - t_begin) & 1;
+        bf16x8* my_ag = agt + ((set * TH + wave) * 8) * 64 + lane;   // vector (mb, ks, part) at [(mb * 4 + ks * 2 + part) * 64]
+        // ---- this tile's operand vectors have landed (requested a tile ago; hipcc does not count LDS-DMA); commit the x tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int it = tid + k * NT;
             if (it < 2 * NPOS) xt[it] = make_float4(xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
         }
         __syncthreads();
+        // ---- the next tile's requests (the last tile asks for itself again: unconditional loads keep hipcc's s_waitcnt bookkeeping simple)
+        int bn, y0n, x0n;
+        tile_coords(t + 1 < t_end ? t + 1 : t, bn, y0n, x0n);
+        fetch_ag(bn, y0n, x0n, set ^ 1);
+        request_x(bn, y0n, x0n);
+        const __amdgpu_buffer_rsrc_t off_rs_n = buf_view(d.offset + (size_t)bn * d.off_bs), msk_rs_n = buf_view(d.mask + (size_t)bn * d.mask_bs);
+        const unsigned pv_n = pixel_offset(y0n, x0n);
 
         f32x16 dt_h, dt_l;   // column values of two lane iterations, transposed: D[i = pixel][j = 16 (it & 1) + 8 h + ch]
 #pragma unroll
@@ -734,6 +744,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
             const bool act_lane = px_ok && has_tap;
             const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
             float m = o_m[it];
+            request_offsets(it, off_rs_n, msk_rs_n, pv_n);   // (the registers just read: the next tile's triple of this iteration)
             if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
             const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
             // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616)
@@ -800,7 +811,6 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
             }
             if ((it & 1) || it == 4) {   // ---- n-block nb = it / 2 complete: gw_acc[mb][nb] += gOut^T[mb] x col, K = this row's 32 pixels
                 const int nb = it >> 1;
-                if (it == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's operand vectors have landed (hipcc does not count LDS-DMA)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8 bh = pack8_exact(dt_h, 8 * ks);
@@ -816,9 +826,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
                 }
             }
         }
-        if (t + 1 < t_end) fetch_ag(t + 1);   // (the MFMAs above consumed this tile's vectors: the slots are free)
         __syncthreads();   // (every wave is done with the x tile)
-        if (t + 1 < t_end) request(t + 1);
     }
 
     // ---- partial of this (stream, unit): sum of the 4 waves (rows), fixed order, through LDS
@@ -883,7 +891,7 @@ int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* g
         (size_t)64 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
         return RVSR_ERR_UNSUPPORTED;
     constexpr int R = 4, TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
-    const size_t lds = (size_t)NPOS * 32 + (size_t)TH * 8 * 64 * 16;
+    const size_t lds = (size_t)NPOS * 32 + (size_t)2 * TH * 8 * 64 * 16;
     DcnBwdW6Params p;
     p.d = d; p.agt = (const bf16x8*)agt; p.agt_nmb32 = 2 * nmb; p.agt_rows = ((d.Ho + 7) / 8) * 8;
     const size_t nw = (size_t)d.Co * d.C * 9;
