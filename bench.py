@@ -28,7 +28,9 @@ Extra objects on the line:
                   8 TB/s HBM3E peak.  `traffic` is NOT measured in this run: it is the PMC measurement kept under
                   profiles/ rescaled to this run's launch size (`traffic_source` names the file).
   roofline_conv -- the 3x3 nf->nf convolution (conv_fwd5_kernel) on all B*N frames, timed live after the timed region: MFMA
-                  work issued (3 bf16 passes per product) vs the 2.5 PFLOP/s dense bf16 peak, and the f32-equivalent rate.
+                  work issued (3 bf16 passes per product) vs the 2.5 PFLOP/s dense bf16 peak, and the f32-equivalent rate;
+                  `sustained_peak` / `frac_of_sustained`: the MFMA rate this box sustains on a register-resident MFMA stream whose
+                  operands carry data (measured live; ~0.67 of nominal: the package power limit) and the kernel's fraction of THAT.
   cpu_baseline -- the CPU oracle (oracle/edvr_oracle.py, kind "port") on ONE window of the same workload (B=1),
                   1 warm-up + best-of-3, timed on this box's host cores (rank 0, N=1 only).
   parity       -- the same seeded window, same weights, through the HIP model: output / loss / every parameter gradient against
@@ -230,6 +232,37 @@ class _Proxy:
         RF._lib._lib = _Proxy._real
 
 
+def sustained_mfma_tflops(dev, pattern='split'):
+    """The bf16 MFMA rate this box SUSTAINS on operands that carry data (measured live, ~0.1 s): a register-resident stream of
+    v_mfma_f32_32x32x16_bf16 (rvsr_debug_mfma_rate: nothing but the matrix pipe runs) on `pattern` operands: 'ones' (constant: the
+    nominal peak), 'normal' (random sign / exponent / mantissa) or 'split' (the bf16x3 kernels' operand mix: N(0,1)-like hi parts and
+    lo parts ~2^-9 of them).  With data the package power limit, not the kernel, caps the matrix pipe at ~0.67 of 2.5 PFLOP/s
+    (profiles/r05_mfma_power_micro.txt): the second denominator reported next to the guide's nominal peak."""
+    from realvsr_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(1)
+    n = 8 * 512 * 8
+    if pattern == 'ones':
+        ops = torch.ones(n)
+    else:
+        ops = torch.randn(n, generator=g)
+        if pattern == 'split':
+            ops.view(8, -1)[1::2] *= 2.0 ** -9
+    ops = ops.to(torch.bfloat16).to(dev)
+    out = torch.empty(256 * 512, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    iters = 150000
+    L.rvsr_debug_mfma_rate(ops.data_ptr(), out.data_ptr(), 256, 2000, st)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = L.rvsr_debug_mfma_rate(ops.data_ptr(), out.data_ptr(), 256, iters, st)
+    e.record()
+    torch.cuda.synchronize()
+    if rc != 0:
+        return None
+    return 256 * 8 * iters * 8 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
+
+
 def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
     """Second roofline object (outside the timed region): the 3x3 nf->nf convolution of the feature extractor on all B*N
     frames -- the shape ~80 % of a step's GEMM work runs at -- timed live with HIP events on the launching stream.  `achieved`
@@ -252,10 +285,20 @@ def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
     passes = GEMM_PASSES[gemm_mode]
     peak = MFMA_F32_PEAK_TFLOPS if gemm_mode == 'f32' else MFMA_BF16_PEAK_TFLOPS
     ach = passes * flop / (ms * 1e-3) / 1e12
-    return {'kernel': 'conv_fwd5_kernel (+ its weight pre-pack): 3x3 %d->%d + ReLU on %d frames of %dx%d' % (nf, nf, frames, H, W),
-            'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'mfma_passes_per_product': passes, 'f32_equivalent': round(flop / (ms * 1e-3) / 1e12, 1),
-            'avg_launch_ms': round(ms, 4), 'traffic': None}
+    r = {'kernel': 'conv_fwd5_kernel (+ its weight pre-pack): 3x3 %d->%d + ReLU on %d frames of %dx%d' % (nf, nf, frames, H, W),
+         'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+         'mfma_passes_per_product': passes, 'f32_equivalent': round(flop / (ms * 1e-3) / 1e12, 1),
+         'avg_launch_ms': round(ms, 4), 'traffic': None}
+    if gemm_mode != 'f32':
+        sus = sustained_mfma_tflops(conv.weight.device, 'split' if gemm_mode != 'bf16' else 'normal')
+        ones = sustained_mfma_tflops(conv.weight.device, 'ones')
+        if sus:
+            r['sustained_peak'] = round(sus, 1)
+            r['frac_of_sustained'] = round(ach / sus, 4)
+            r['sustained_peak_note'] = ('measured live on this box: register-resident v_mfma_f32_32x32x16_bf16 stream on operands with this '
+                                        "mode's data pattern (package power limit); the same stream on constant operands: %s TFLOP/s"
+                                        % (round(ones, 1) if ones else None))
+    return r
 
 
 class _Snapshot:
@@ -808,10 +851,12 @@ def main():
         }
         if kms > 0:
             # what the fused DCN forward is actually bound by (profiles/r04_notes.md): not HBM -- its traffic is 1.12x the algorithmic bytes --
-            # but what one pixel costs on chip.  The LDS side of that: gather + weight-fragment bytes vs 256 B/clk/CU x 256 CUs x 2.4 GHz;
+            # but what one pixel costs on chip.  The LDS side of that: gather + weight-fragment bytes vs the measured 146 B/clk/CU x 256 CUs x 2.4 GHz;
             # bank conflicts of the per-pixel gather (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.41 at i.i.d. offsets) multiply the LDS
             # cycles by ~1.7, and the SIMDs' instruction issue (412 instructions per four (wave, tap)s, SQ_ACTIVE_INST_ANY 84 %) is the other half
-            lds_peak = 256 * 256 * 2.4e9 / 1e12
+            # peak: the micro-benchmarked ds_read_b128 rate (profiles/r03_lds_micro.txt: 7 clk per 1 KB wave instruction per CU = 146 B/clk)
+            # at the 2.4 GHz nominal clock -- round 4 used the 256 B/clk of the CDNA4 data sheet, which no instruction mix here reaches
+            lds_peak = 256 * (1024 / 7.0) * 2.4e9 / 1e12
             lds_ach = timer.lds_bytes / (kms * 1e-3) / 1e12
             line['roofline_lds'] = {'kernel': 'dcn_fwd3_kernel', 'bound': 'lds', 'achieved': round(lds_ach, 2), 'peak': round(lds_peak, 1), 'unit': 'TB/s',
                                     'frac': round(lds_ach / lds_peak, 4), 'bytes_per_pixel': round(timer.lds_bytes / max(kbytes, 1) * 4.0 * (args.nf + 216 + args.nf)),

@@ -382,6 +382,11 @@ int rvsr_augment_clips(const float* im1, const float* im2, float* out1, float* o
 int rvsr_bcast_add_act(float* a, const float* b, size_t per, int N, int act, float slope, void* stream);
 int rvsr_bcast_reduce_act(const float* gout, const float* out, float* gb, size_t per, int N, float gslope, void* stream);
 
+/* Measurement aid, not part of the reference's interface (bench.py: roofline_conv.sustained_peak): `workgroups` x 8 waves loop `iters`
+ * times over 8 register-resident v_mfma_f32_32x32x16_bf16 whose operands come from `ops` (8 x 512 x 16 B of bf16: [operand][thread][8]);
+ * out: workgroups x 512 floats (checksums).  MFMA work issued = workgroups * 8 waves * iters * 8 * 32768 FLOP. */
+int rvsr_debug_mfma_rate(const void* ops, float* out, int workgroups, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ SIGNATURES = {
     'rvsr_bcast_add_act': (c_int, [c_fp, c_fp, c_size, c_int, c_int, c_float, c_fp]),
     'rvsr_bcast_reduce_act': (c_int, [c_fp, c_fp, c_fp, c_size, c_int, c_float, c_fp]),
     'rvsr_augment_clips': (c_int, [c_fp] * 5 + [c_size] + [c_int] * 10 + [c_float, c_fp]),
+    'rvsr_debug_mfma_rate': (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
 }
 
 

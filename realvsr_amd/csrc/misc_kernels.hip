@@ -686,3 +686,33 @@ extern "C" int rvsr_ycbcr_to_bgr_u8(const float* ycc, unsigned char* bgr, int H,
     hipLaunchKernelGGL(ycbcr2bgr_u8_kernel, GRID_FOR(hw), dim3(256), 0, (hipStream_t)stream, ycc, bgr, hw);
     CHECK_LAUNCH("ycbcr_to_bgr_u8");
 }
+
+// ------------------------------------------------------------------------------------------
+// Measurement aid (bench.py: roofline_conv.sustained_peak): the rate this device SUSTAINS on v_mfma_f32_32x32x16_bf16 with operands
+// that carry data.  One 8-wave workgroup per CU, every wave loops over 8 MFMAs on 8 accumulator sets with 4 + 4 operand registers taken
+// from `ops` (8 x 512 x 16 B): nothing but the matrix pipe runs.  Constant operands reach the nominal 2.5 PFLOP/s; N(0,1)-like values or
+// the three-term hi / lo pattern run into the package power limit at ~0.67 of it (profiles/r05_mfma_power_micro.txt).
+typedef __bf16 dbg_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void mfma_rate_kernel(const dbg_bf16x8* __restrict__ ops, float* out, int iters) {
+    f32x16 a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = zero16();
+    dbg_bf16x8 x[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[i] = ops[(i * 2) * 512 + threadIdx.x]; y[i] = ops[(i * 2 + 1) * 512 + threadIdx.x]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i & 3], y[(i + (i >> 2)) & 3], a[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += a[i][j];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
+}
+extern "C" int rvsr_debug_mfma_rate(const void* ops, float* out, int workgroups, int iters, void* stream) {
+    if (!ops || !out || workgroups <= 0 || iters <= 0) FAIL(RVSR_ERR_BAD_ARG, "debug_mfma_rate: null/empty argument");
+    hipLaunchKernelGGL(mfma_rate_kernel, dim3((unsigned)workgroups), dim3(512), 0, (hipStream_t)stream, (const dbg_bf16x8*)ops, out, iters);
+    CHECK_LAUNCH("debug_mfma_rate");
+}
