@@ -6,11 +6,12 @@
  *   - plain device pointers (float32, NCHW, contiguous unless a batch stride is stated) + sizes;
  *     no torch / ATen types.  The caller owns every buffer; the library allocates nothing
  *     (temporaries come in through `workspace`) and keeps no state between calls EXCEPT one
- *     process-wide setting, the GEMM arithmetic (rvsr_set_gemm_mode below: read by every conv /
- *     DCN entry point at call time; set it once before the first call, not concurrently with
- *     calls in flight on other host threads -- the reference's nn.DataParallel threads
- *     (VideoSR_AllPair_model_YCbCr_Split.py:35-36) may all CALL concurrently, each on its own
- *     device / stream; tests/test_gpu_misc.py::test_two_host_threads_two_streams).  The host
+ *     setting, the GEMM arithmetic: a process-wide default (rvsr_set_gemm_mode below; set it once
+ *     before the first call) and a per-host-thread override (rvsr_set_gemm_mode_thread), both read
+ *     by every conv / DCN entry point at call time on the calling thread -- so the reference's
+ *     nn.DataParallel threads (VideoSR_AllPair_model_YCbCr_Split.py:35-36), which all CALL
+ *     concurrently, each on its own device / stream, can each choose without racing
+ *     (tests/test_gpu_misc.py::test_two_host_threads_two_streams, ::test_gemm_mode_per_thread).  The host
  *     mirror realvsr_amd.functional keeps two per-process caches on top (bf16 weight images keyed
  *     on the parameter object, per-layer DCN offset statistics); both are keyed per parameter
  *     object + device, so DataParallel replicas (distinct parameter objects) get their own entries.
@@ -58,7 +59,12 @@ const char* rvsr_last_error(void);
  * the generic DCN path of section 1c) computes three terms in modes 2 / 3, so a network off those shapes gets
  * mode 0's result and speed.  Other values select 0.  Process-wide switch. */
 void rvsr_set_gemm_mode(int mode);
-int rvsr_get_gemm_mode(void);
+int rvsr_get_gemm_mode(void);   /* the mode the CALLING thread's next call computes in */
+/* The same choice for the calling host thread only (every entry point reads the mode at call time on the calling thread): mode 0-3
+ * overrides the process-wide setting for this thread's calls, any other value (-1) returns the thread to the process-wide setting.
+ * This is the race-free way to select the arithmetic per call -- set it, call, set it back -- when several host threads drive the
+ * library at once (the reference's nn.DataParallel replicas); rvsr_set_gemm_mode stays the default for threads that never ask. */
+void rvsr_set_gemm_mode_thread(int mode);
 
 /* ---------------------------------------------------------------------------------------------
  * 1. Modulated deformable convolution (DCNv2)

@@ -41,6 +41,7 @@ SIGNATURES = {
     'rvsr_pack_weights_batched': (c_int, [c_fp, c_int, c_fp]),
     'rvsr_set_gemm_mode': (None, [c_int]),
     'rvsr_get_gemm_mode': (c_int, []),
+    'rvsr_set_gemm_mode_thread': (None, [c_int]),
     'rvsr_conv2d_wgrad_workspace_bytes': (c_size, [c_int] * 8),
     'rvsr_conv2d_backward_weight': (c_int, [c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_float, c_int, c_int,
                                             c_int, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
@@ -124,6 +125,12 @@ def set_gemm_mode(mode):
     The reduced-term modes are opt-in speed modes of conv_fwd5 / conv_wgrad2 / the DCN kernels (every other kernel keeps three terms);
     tests/test_gpu_modes.py holds them to the 1e-3 dB PSNR bound of the north star."""
     lib().rvsr_set_gemm_mode(GEMM_MODES[mode])
+
+
+def set_gemm_mode_thread(mode):
+    """The same choice for the calling host thread only (None: back to the process-wide setting).  Race-free per-call selection when
+    several host threads drive the library (nn.DataParallel replicas): every entry point reads the mode on the calling thread."""
+    lib().rvsr_set_gemm_mode_thread(-1 if mode is None else GEMM_MODES[mode])
 
 
 def get_gemm_mode():

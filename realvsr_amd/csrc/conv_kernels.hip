@@ -346,11 +346,11 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
         // out = (conv + bias) * (residual > 0 ? 1 : slope): the data gradient of a layer whose INPUT was an activation output, with that
         // activation's derivative applied on the way out (`residual` = the saved activation output).  Only the 8 x 64-tile kernel has this
         // epilogue; everything else answers "unsupported" and the caller applies the mask on the consumer side as before.
-        if (!residual || ksize != 3 || stride != 1 || pixel_shuffle || out2 || rvsr_g_gemm_mode == 1) return RVSR_ERR_UNSUPPORTED;
+        if (!residual || ksize != 3 || stride != 1 || pixel_shuffle || out2 || rvsr_gemm_mode_now() == 1) return RVSR_ERR_UNSUPPORTED;
         return rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
     }
     if (rvsr_conv_fwd_thin_ok(p, ksize, stride)) return rvsr_launch_conv_fwd_thin(p, st);   // <= 4 output channels: vector ALU, exact f32
-    if (rvsr_g_gemm_mode != 1 && (in_mode != 1 || ksize == 3) && (x2 == nullptr || C1 % 8 == 0)) {
+    if (rvsr_gemm_mode_now() != 1 && (in_mode != 1 || ksize == 3) && (x2 == nullptr || C1 % 8 == 0)) {
         const int rc2 = rvsr_launch_conv_fwd2(p, ksize, stride, workspace, workspace_bytes, st);
         if (rc2 != RVSR_ERR_UNSUPPORTED) return rc2;   // (sizes beyond the buffer-addressed kernels: exact-f32 kernels below)
     }
@@ -367,9 +367,11 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
 #undef DISPATCH
 }
 
-int rvsr_g_gemm_mode = 0;
+int rvsr_g_gemm_mode = 0;                  // process-wide default
+thread_local int rvsr_t_gemm_mode = -1;    // the calling host thread's own choice (-1: follow the default)
 extern "C" void rvsr_set_gemm_mode(int mode) { rvsr_g_gemm_mode = (mode >= 0 && mode <= 3) ? mode : 0; }
-extern "C" int rvsr_get_gemm_mode() { return rvsr_g_gemm_mode; }
+extern "C" void rvsr_set_gemm_mode_thread(int mode) { rvsr_t_gemm_mode = (mode >= 0 && mode <= 3) ? mode : -1; }
+extern "C" int rvsr_get_gemm_mode() { return rvsr_gemm_mode_now(); }
 extern "C" size_t rvsr_conv2d_forward_workspace_bytes(int C1, int C2, int Co, int ksize) {
     return rvsr_conv_fwd2_workspace_bytes(ksize, Co, C1 + C2);
 }
@@ -478,14 +480,14 @@ extern "C" int rvsr_conv2d_backward_weight(const float* x1, int C1, const float*
     // conv_wgrad2 addresses one image of each tensor with 32-bit byte offsets (raw buffers, < 2 GB) and picks the input per
     // 64-channel block: a second input has to start on a multiple of 64 channels
     const size_t img_max = sizeof(float) * (size_t)Hout * Wout * (size_t)(Co > Ctot ? Co : Ctot);
-    if (rvsr_g_gemm_mode != 1 && ksize == 3 && stride == 1 && (Wout % 4) == 0 && aligned16 && img_max < ((size_t)1 << 31) &&
+    if (rvsr_gemm_mode_now() != 1 && ksize == 3 && stride == 1 && (Wout % 4) == 0 && aligned16 && img_max < ((size_t)1 << 31) &&
         (C2 == 0 || C1 % 64 == 0))
         rc = rvsr_launch_conv_wgrad2(p, gy, gz, st);
-    else if (rvsr_g_gemm_mode != 1 && ksize == 1 && g_mode == 0 && ((Hout * Wout) % 8) == 0 && aligned16)
+    else if (rvsr_gemm_mode_now() != 1 && ksize == 1 && g_mode == 0 && ((Hout * Wout) % 8) == 0 && aligned16)
         rc = rvsr_launch_conv_wgrad1x1(p, gy, gz, st);
     else if (ksize == 3 && stride == 1)
         rc = launch_wgrad<3, 1, 64>(p, gy, gz, st);
-    else if (ksize == 3 && rvsr_g_gemm_mode != 1 && x2 == nullptr && g_mode == 0 && (Wout % 8) == 0 && (Win % 4) == 0 && aligned16) {
+    else if (ksize == 3 && rvsr_gemm_mode_now() != 1 && x2 == nullptr && g_mode == 0 && (Wout % 8) == 0 && (Win % 4) == 0 && aligned16) {
         const int gz64 = (Ctot + 63) / 64;
         p.P = wgrad_s2_P(B, Hout, Wout, gy, gz64);
         p.bpart = grad_bias ? p.part + (size_t)p.P * nw : nullptr;

@@ -475,7 +475,7 @@ int rvsr_launch_dcn_bwdw2(const DcnGeom& d, const TView& g, float* part, float* 
     p.d = d; p.g = g; p.part = part; p.bpart = bpart_or_null; p.P = P; p.nty = nty;
     p.gvec = ((((uintptr_t)g.p) | ((uintptr_t)g.act)) & 15) == 0;
     constexpr int TR = 4 + 2 * D2_R + 2, TC = 32 + 2 * D2_R + 2;
-    if (rvsr_g_gemm_mode != 1) {  // bf16 split products
+    if (rvsr_gemm_mode_now() != 1) {  // bf16 split products
         const size_t lds3 = (size_t)16 * 2 * TR * TC + (size_t)2 * (64 + 96) * 272;
         // (dcn_bwdw4 addresses 64 gOut planes, 27 offset / mask planes and 8 x planes with 32-bit byte offsets inside 2 GB buffer views)
         const bool spans_ok = (size_t)256 * d.Ho * d.Wo < ((size_t)1 << 31) && (size_t)32 * d.H * d.W < ((size_t)1 << 31);

@@ -382,7 +382,7 @@ static int dcn_forward_impl(DcnGeom& d, const float* weight, const float* bias, 
     DcnFwdParams p;
     p.d = d; p.w = weight; p.bias = bias; p.out = out; p.act = act & 0xff; p.slope = slope; p.prepacked = prepacked;
     p.sel = dcn_halo_always();
-    if (rvsr_g_gemm_mode != 1 && workspace != nullptr) {  // bf16x3 second-generation kernel
+    if (rvsr_gemm_mode_now() != 1 && workspace != nullptr) {  // bf16x3 second-generation kernel
         // `probe`: three zeroed device counters; filled with the offset statistic that selects the tile halo on the device (and that
         // the backward of the same layer reuses)
         size_t nprobe = 0;
@@ -461,12 +461,12 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     static const int genw = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 6; }();   // developer A/B switch
     void* agt = nullptr;
     bool agt_written = false;
-    if (gx && gw && rvsr_g_gemm_mode != 1 && genw >= 6 && d.stride == 1 && d.dil == 1 && d.C % 8 == 0 && d.Co <= 128)
+    if (gx && gw && rvsr_gemm_mode_now() != 1 && genw >= 6 && d.stride == 1 && d.dil == 1 && d.C % 8 == 0 && d.Co <= 128)
         agt = (unsigned char*)workspace + dcn_backward_workspace_base(d.B, d.C, d.H, d.W, d.Co, d.stride, d.pad, d.dil);
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
-        if (rvsr_g_gemm_mode != 1) {
+        if (rvsr_gemm_mode_now() != 1) {
             static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();  // developer A/B switch
             static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
             if (gen >= 7) {

@@ -260,5 +260,7 @@ __device__ __forceinline__ void buf_atomic_add(__amdgpu_buffer_rsrc_t rs, unsign
 // rounded to bf16, the other operand stays a hi + lo pair); 3 = plain bf16 operands (one term).  Accumulation is f32 in every mode.  The
 // reduced-term modes exist in the kernels that dominate a training step (conv_fwd5, conv_wgrad2, the DCN kernels); every other
 // split-GEMM kernel keeps three terms in all of them.
-extern int rvsr_g_gemm_mode;
-static inline int rvsr_gemm_terms() { return rvsr_g_gemm_mode == 2 ? 2 : (rvsr_g_gemm_mode == 3 ? 1 : 3); }
+extern int rvsr_g_gemm_mode;                 // process-wide default (rvsr_set_gemm_mode)
+extern thread_local int rvsr_t_gemm_mode;    // the calling host thread's choice (rvsr_set_gemm_mode_thread), -1 = the default
+static inline int rvsr_gemm_mode_now() { return rvsr_t_gemm_mode >= 0 ? rvsr_t_gemm_mode : rvsr_g_gemm_mode; }
+static inline int rvsr_gemm_terms() { const int m = rvsr_gemm_mode_now(); return m == 2 ? 2 : (m == 3 ? 1 : 3); }

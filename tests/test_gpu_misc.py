@@ -198,6 +198,49 @@ def test_two_host_threads_two_streams():
             assert torch.equal(got[i], ref[i]), i
 
 
+def test_gemm_mode_per_thread():
+    """include/realvsr_hip.h rvsr_set_gemm_mode_thread (the arithmetic selectable per call without a process-wide race):
+    two host threads run the same convolution concurrently, one in the exact-f32 mode and one in the default split mode; each gets
+    bit for bit what a single-threaded run in its mode gives, and the process-wide setting is untouched."""
+    import threading
+    from realvsr_amd import functional as RF, _lib
+    d = dev()
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1).to(d)
+    x = torch.randn(2, 64, 40, 64, device=d)
+    before = _lib.get_gemm_mode()
+    ref = {}
+    for mode in ('f32', 'bf16x3'):
+        _lib.set_gemm_mode_thread(mode)
+        assert _lib.get_gemm_mode() == mode
+        with torch.no_grad():
+            ref[mode] = RF.conv2d(x, conv, RF.ACT_LRELU).clone()
+    _lib.set_gemm_mode_thread(None)
+    assert _lib.get_gemm_mode() == before
+    torch.cuda.synchronize()
+    assert not torch.equal(ref['f32'], ref['bf16x3'])      # (the two modes do differ in the last bits)
+    got = {}
+    streams = {m: torch.cuda.Stream() for m in ref}
+
+    def threaded(mode):
+        _lib.set_gemm_mode_thread(mode)
+        with torch.cuda.stream(streams[mode]), torch.no_grad():
+            y = None
+            for _ in range(8):
+                y = RF.conv2d(x, conv, RF.ACT_LRELU)
+            got[mode] = y
+        streams[mode].synchronize()
+
+    ts = [threading.Thread(target=threaded, args=(m,)) for m in ref]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for m in ref:
+        assert torch.equal(got[m], ref[m]), m
+    assert _lib.get_gemm_mode() == before
+
+
 def test_dcn_offset_stats_lag_is_counted_in_optimizer_steps():
     """functional.DcnOffsetStats: a forward decides from the layer's counters of LAG optimizer steps back, whatever the number of
     backwards the layer has per step (the per-frame PCD path has N); without anybody calling advance() the lag counts the layer's own
