@@ -263,7 +263,7 @@ def sustained_mfma_tflops(dev, pattern='split'):
     return 256 * 8 * iters * 8 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
 
 
-def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
+def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10, sustained=True):
     """Second roofline object (outside the timed region): the 3x3 nf->nf convolution of the feature extractor on all B*N
     frames -- the shape ~80 % of a step's GEMM work runs at -- timed live with HIP events on the launching stream.  `achieved`
     counts the MFMA work actually issued (3 bf16 passes per f32 product in bf16x3 mode) against the dense bf16 peak;
@@ -289,7 +289,7 @@ def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10):
          'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
          'mfma_passes_per_product': passes, 'f32_equivalent': round(flop / (ms * 1e-3) / 1e12, 1),
          'avg_launch_ms': round(ms, 4), 'traffic': None}
-    if gemm_mode != 'f32':
+    if gemm_mode != 'f32' and sustained:   # (skipped with --no-sweep: the rocprofv3 kernel statistics then hold the step's kernels only)
         sus = sustained_mfma_tflops(conv.weight.device, 'split' if gemm_mode != 'bf16' else 'normal')
         ones = sustained_mfma_tflops(conv.weight.device, 'ones')
         if sus:
@@ -864,7 +864,7 @@ def main():
                                             'measured bank conflicts multiply the LDS cycles by ~1.7 (profiles/r03_dcn_sq_counters.json)'}
         if allreduce is not None:
             line['allreduce'] = allreduce
-        line['roofline_conv'] = conv_roofline(model.netG, B * N, args.nf, H, W, gemm_mode)
+        line['roofline_conv'] = conv_roofline(model.netG, B * N, args.nf, H, W, gemm_mode, sustained=not args.no_sweep)
         if world == 1 and not args.no_sweep:
             nxt = args.warmup + args.steps + 1
             line['offset_sweep'] = offset_sweep(model, x, nxt, native if args.offset_px is not None else None,
