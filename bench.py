@@ -25,8 +25,9 @@ B 16 (per GPU: with --gpus 8 this is BASELINE config 4); 5 = 540x960 sliding-win
 Extra objects on the line:
   roofline     -- the fused DCN forward kernel (the kernel north_star grades): algorithmic bytes 4*(C+216+Co) per
                   output pixel summed over the timed DCN launches / their HIP-event durations, vs the
-                  8 TB/s HBM3E peak.  `traffic` is NOT measured in this run: it is the PMC measurement kept under
-                  profiles/ rescaled to this run's launch size (`traffic_source` names the file).
+                  8 TB/s HBM3E peak.  `traffic`: HBM bytes per launch from PMC counters -- measured in this run when rocprofv3 is on
+                  the box (two short child processes after the timed region: --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of
+                  tools/dcn_micro.py, rescaled to this line's launch size), else the record kept under profiles/ (`traffic_source` says which).
   roofline_conv -- the 3x3 nf->nf convolution (conv_fwd5_kernel) on all B*N frames, timed live after the timed region: MFMA
                   work issued (3 bf16 passes per product) vs the 2.5 PFLOP/s dense bf16 peak, and the f32-equivalent rate;
                   `sustained_peak` / `frac_of_sustained`: the MFMA rate this box sustains on a register-resident MFMA stream whose
@@ -261,6 +262,51 @@ def sustained_mfma_tflops(dev, pattern='split'):
     if rc != 0:
         return None
     return 256 * 8 * iters * 8 * 32768.0 / (s.elapsed_time(e) * 1e-3) / 1e12
+
+
+def measure_dcn_traffic(nf, timeout=150):
+    """HBM bytes per output pixel of the fused DCN forward, MEASURED in this run: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate
+    runs, --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of tools/dcn_micro.py at the L1 shape (B*N frames of
+    180x320, offset std 1.25 px), each in its own process.  gfx950: FETCH_SIZE x 2 (it reports half of the coalesced reads, profiles/r01_notes.md),
+    both counters in KB.  Returns (bytes_per_pixel, note) or (None, reason); the caller falls back to the record kept under profiles/."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not on PATH'
+    B = 40 if nf == 64 else 16
+    vals = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='rvsr_pmc_', dir='/tmp')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            subprocess.run([exe, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
+                            os.path.join(ROOT, 'tools', 'dcn_micro.py'), '--iters', '2', '--B', str(B), '--C', str(nf), '--ostd', '1.25', '--fwd-only'],
+                           cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=False)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            per = {}
+            for fn in files:
+                with open(fn) as f:
+                    for row in csv.DictReader(f):
+                        name = row.get('Kernel_Name', '')
+                        if 'dcn_fwd3' in name and row.get('Counter_Name') == ctr:
+                            acc = per.setdefault(name, [0.0, 0])
+                            acc[0] += float(row['Counter_Value'])
+                            acc[1] += 1
+            if not per:
+                return None, 'no %s rows for dcn_fwd3 in the rocprofv3 output' % ctr
+            vals[ctr] = max(v / n for v, n in per.values())   # (the halo candidates that return at once count ~0: keep the one that worked)
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            return None, '%s pass failed: %s' % (ctr, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    px = B * 180 * 320
+    hbm = (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+    return hbm / px, ('measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate processes, --kernel-trace) of '
+                      'tools/dcn_micro.py --B %d --C %d --ostd 1.25 --fwd-only; FETCH_SIZE x 2 + WRITE_SIZE = %.1f B per output pixel, rescaled to '
+                      "this line's average launch size" % (B, nf, hbm / px))
 
 
 def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10, sustained=True):
@@ -816,6 +862,14 @@ def main():
                 % (PMC_PROFILE[args.nf], pmc['shape'].get('offset_std_px'))
     except (OSError, KeyError, ValueError):
         pass
+    if rank == 0 and world == 1 and nl > 0 and not args.no_sweep and H == 180 and W == 320:
+        # ... and measured live when rocprofv3 is on this box (two child processes, ~30 s; the timed region is long over)
+        bpp, note = measure_dcn_traffic(args.nf)
+        if bpp is not None:
+            traffic = round(bpp * (kbytes / nl) / (4.0 * (args.nf + 216 + args.nf)))
+            traffic_source = note
+        elif traffic_source is not None:
+            traffic_source += '; live PMC pass unavailable: ' + note
 
     if rank == 0:
         l1 = off.get('pcd_align.L1_dcnpack', (None, None))
