@@ -19,6 +19,15 @@
 
 #include "bf16x3.h"
 
+// Energy ablations of scratch builds (tools/build_variant.sh conv2_kernels <name> -DRVSR_ABL5=<bits>; results wrong by construction; the 8 x 64
+// kernel runs at the package power cap, so its time follows the energy of what it does -- profiles/r05_notes.md): 1 = LDS fragment reads of
+// taps 2-8 dropped, 2 = output stores dropped, 4 = input loads dropped
+#ifdef RVSR_ABL5
+constexpr int ABL5 = RVSR_ABL5;
+#else
+constexpr int ABL5 = 0;
+#endif
+
 #ifdef RVSR_TIMELINE
 __device__ unsigned long long rvsr_dbg[512];
 extern "C" int rvsr_debug_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg), sizeof(unsigned long long) * 512); }
@@ -204,6 +213,7 @@ __device__ __forceinline__ void conv2_epilogue_wide(f32x16 (&acc)[MT][2], const 
                     v.x *= resv[s].x > 0.f ? 1.f : p.slope; v.y *= resv[s].y > 0.f ? 1.f : p.slope;
                     v.z *= resv[s].z > 0.f ? 1.f : p.slope; v.w *= resv[s].w > 0.f ? 1.f : p.slope;
                 }
+                if (!(ABL5 & 2) || (m == 0 && rg == 0 && s == 0))   // (ABL5 & 2: one store in 16 kept so that the epilogue's arithmetic stays alive)
                 buf_store4(out_rs, off[s] + (unsigned)(o0 + m * 32 + 8 * rg + 4 * s) * HW4, 0u, v);
             }
         }
@@ -823,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #ifdef RVSR_TIMELINE
             if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[300 + wave * 12 + tap] = __builtin_amdgcn_s_memtime();
 #endif
-            if (tap + 1 < T) fetch(tap + 1, sl ^ 1);
+            if (tap + 1 < ((ABL5 & 1) ? 2 : T)) fetch(tap + 1, sl ^ 1);   // (ABL5 & 1: fragments of taps 0 and 1 reused for taps 2-8)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -849,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
             } else {
                 if (pub) commit(buf ^ 1, tap - 4, 8);
                 if (tap == 4) stage_tile(q + 2, k_nx2, c_nx2);
-                issue_stage(q + 2, c_nx2, tap - 4, VEC ? (tap < 6 ? tap - 4 : 8) : (tap - 4 < NIT ? tap - 4 : 8));
+                issue_stage(q + 2, c_nx2, tap - 4, (ABL5 & 4) ? 8 : VEC ? (tap < 6 ? tap - 4 : 8) : (tap - 4 < NIT ? tap - 4 : 8));   // (ABL5 & 4: no input loads after the first stages)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
