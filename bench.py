@@ -318,7 +318,7 @@ def conv_roofline(net, frames, nf, H, W, gemm_mode, reps=10, sustained=True):
     conv = net.feature_extraction[0].conv1
     x = torch.randn(frames, nf, H, W, device=conv.weight.device)
     with torch.no_grad():
-        for _ in range(3):
+        for _ in range(10):
             RF.conv2d(x, conv, act=RF.ACT_RELU)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -862,14 +862,6 @@ def main():
                 % (PMC_PROFILE[args.nf], pmc['shape'].get('offset_std_px'))
     except (OSError, KeyError, ValueError):
         pass
-    if rank == 0 and world == 1 and nl > 0 and not args.no_sweep and H == 180 and W == 320:
-        # ... and measured live when rocprofv3 is on this box (two child processes, ~30 s; the timed region is long over)
-        bpp, note = measure_dcn_traffic(args.nf)
-        if bpp is not None:
-            traffic = round(bpp * (kbytes / nl) / (4.0 * (args.nf + 216 + args.nf)))
-            traffic_source = note
-        elif traffic_source is not None:
-            traffic_source += '; live PMC pass unavailable: ' + note
 
     if rank == 0:
         l1 = off.get('pcd_align.L1_dcnpack', (None, None))
@@ -963,6 +955,16 @@ def main():
             except Exception as e:
                 extra['config5'] = {'error': repr(e)[:300]}
             line['extra'] = extra
+        if world == 1 and nl > 0 and not args.no_sweep and H == 180 and W == 320:
+            # roofline.traffic measured live when rocprofv3 is on this box (two child processes, ~15 s, as the last thing before the line is printed:
+            # every timed measurement of this process ran on a warm GPU); the record kept under profiles/ stays as the fallback
+            torch.cuda.empty_cache()
+            bpp, note = measure_dcn_traffic(args.nf)
+            if bpp is not None:
+                line['roofline']['traffic'] = round(bpp * (kbytes / nl) / (4.0 * (args.nf + 216 + args.nf)))
+                line['roofline']['traffic_source'] = note
+            elif line['roofline'].get('traffic_source') is not None:
+                line['roofline']['traffic_source'] += '; live PMC pass unavailable: ' + note
         print(json.dumps(line), flush=True)
     if use_pg:
         torch.distributed.destroy_process_group()
