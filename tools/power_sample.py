@@ -35,7 +35,27 @@ def fwdbwd():
     y.backward(x)
 
 
-cases = [c for c in [('idle', None), ('conv_fwd5 forward', fwd), ('conv fwd + dgrad + wgrad', fwdbwd), ('MFMA stream, operands 1.0', mfma('ones')),
+gd = torch.Generator().manual_seed(0)
+dx = torch.randn(40, 64, 180, 320, generator=gd).to(dev)
+dom = torch.randn(40, 216, 180, 320, generator=gd)
+dom[:, :144] *= 1.25
+dom = dom.to(dev)
+dw = (torch.randn(64, 64, 3, 3, generator=gd) / 24).to(dev)
+db = torch.zeros(64, device=dev)
+dxg, domg, dwg = dx.clone().requires_grad_(True), dom.clone().requires_grad_(True), dw.clone().requires_grad_(True)
+
+
+def dcn_fwd():
+    with torch.no_grad():
+        RF.dcn_pack(dx, dom, dw, db, 1, 1, 1, 8, RF.ACT_LRELU, 0.1)
+
+
+def dcn_fwdbwd():
+    out = RF.dcn_pack(dxg, domg, dwg, db, 1, 1, 1, 8, RF.ACT_LRELU, 0.1)
+    out.backward(dx)
+
+
+cases = [c for c in [('idle', None), ('DCN forward (B = 40, 1.25 px)', dcn_fwd), ('DCN forward + backward', dcn_fwdbwd), ('conv_fwd5 forward', fwd), ('conv fwd + dgrad + wgrad', fwdbwd), ('MFMA stream, operands 1.0', mfma('ones')),
          ('MFMA stream, N(0,1) operands', mfma('normal'))] if not os.environ.get('RVSR_POWER_ONLY') or os.environ['RVSR_POWER_ONLY'] in c[0]]
 for name, fn in cases:
     stop = [False]
