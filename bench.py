@@ -447,8 +447,10 @@ def f32_mode_step(model, first_step, steps=2):
 GEMM_DESC = {'bf16x3': ' (3-term bf16 split on v_mfma_f32_32x32x16_bf16, f32 accumulate)',
              'bf16x2': ' (2-term bf16 split: weights rounded to bf16, activations hi + lo; v_mfma_f32_32x32x16_bf16, f32 accumulate)',
              'bf16': ' (bf16 operands on v_mfma_f32_32x32x16_bf16, f32 accumulate)',
+             'f16fp8': ' (forward 3x3 convs: f16 main term + fp8 e4m3 cross terms on v_mfma_f32_32x32x16_f16 / v_mfma_scale_f32_32x32x64_f8f6f4, '
+                       '~1.2e-5 per conv instead of 4.6e-6; gradients and every other kernel: the 3-term bf16 split)',
              'f32': ' (v_mfma_f32_32x32x2_f32, exact f32)'}
-GEMM_PASSES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'f32': 1}
+GEMM_PASSES = {'bf16x3': 3, 'bf16x2': 2, 'bf16': 1, 'f32': 1, 'f16fp8': 3}
 
 
 def dtype_of(gemm_mode):
@@ -664,6 +666,14 @@ def infer_line(a, T=10, offset_px=None):
             rlib.set_gemm_mode('bf16x3')
         res['speed_mode_bf16'] = {'ms_per_frame': round(ms1, 2), 'value': round(1e3 / ms1, 3),
                                   'max_abs_diff_of_the_output': float('%.3e' % (out1 - out).abs().max().item())}
+        del out1
+        rlib.set_gemm_mode('f16fp8')   # forward 3x3 convs in the f16 + fp8 product format, everything else three-term
+        try:
+            out1, ms1 = timed(run)
+        finally:
+            rlib.set_gemm_mode('bf16x3')
+        res['speed_mode_f16fp8'] = {'ms_per_frame': round(ms1, 2), 'value': round(1e3 / ms1, 3),
+                                    'max_abs_diff_of_the_output': float('%.3e' % (out1 - out).abs().max().item())}
         del out1
     del net, clip, out, out_g, run, run_g
     return res
@@ -919,7 +929,7 @@ def main():
                 line['f32_mode_ms_per_step'] = f32_mode_step(model, nxt)
                 # the opt-in speed modes (realvsr_amd.set_gemm_mode): same step, 2 untimed + 3 timed; their parity rows follow below
                 line['speed_modes'] = {}
-                for m in ('bf16x2', 'bf16'):
+                for m in ('f16fp8', 'bf16x2', 'bf16'):
                     r_m = gemm_mode_step(model, nxt, m, steps=3)
                     line['speed_modes'][m] = dict({'gemm': m + GEMM_DESC[m], 'frames_per_s': round(B * world * 1e3 / r_m['ms_per_step'], 2)}, **r_m)
         if world == 1 and not args.no_cpu_baseline:

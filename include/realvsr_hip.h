@@ -205,6 +205,13 @@ int rvsr_deform_conv_generic_backward(int dtype, const void* input, const void* 
  *   weight: w_mode 0 -> (Co, C1+C2, k, k) used as is;
  *           w_mode 1 -> (C1+C2, Co, k, k) used transposed + spatially flipped (data gradient);
  *           w_mode | 2: `workspace` already holds the packed image of these weights (section 2b), the per-call pack is skipped.
+ *           w_mode | 4 (opt-in, with w_mode & 1 == 0, ksize 3, stride 1, Co1+Co2 > 32, in_mode 0, xact NULL, Ws % 4 == 0, 16-byte aligned
+ *               inputs, a second input only behind a multiple of 16 channels; RVSR_ERR_UNSUPPORTED otherwise): this forward conv forms its
+ *               products in the f16 + fp8 format -- a1*b1 on v_mfma_f32_32x32x16_f16 plus the cross terms a1*b2 + a2*b1 on
+ *               v_mfma_scale_f32_32x32x64_f8f6f4 (a1 = f16(a), a2 = a - a1, fp8 e4m3 with the 2^12 in the block scales): 56 instead of
+ *               108 matrix instructions per 16-channel stage, ~1.2e-5 instead of ~4.6e-6 relative l2 error per convolution (f32: 3e-7).
+ *               Activations must lie inside f16's range (|x| < 65504; below 6e-8 they round to zero).  A packed image (w_mode | 2) must
+ *               have been written with the same flag.  realvsr_amd.set_gemm_mode('f16fp8') sets it on every eligible forward conv.
  *   out1 (B,Co1,Hout,Wout) [+ out2 (B,Co2,Hout,Wout): rows split, for the gradient of a cat].
  *   residual (NULL or shaped like out1, out2 must be NULL): added after the activation.
  *   act: 0 none, 1 ReLU, 2 LeakyReLU(slope); 3 (with `residual`, ksize 3, stride 1, one output): out = (conv + bias) * (residual > 0 ? 1 : slope),
@@ -228,7 +235,8 @@ int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int C2, const 
 
 /* 2b. Packed weight images, once per optimizer step.  The matrix-core kernels stage weights as bf16 hi/lo images
  *   ([m-block][chunk][hi|lo][tap][octet][row][8]); rvsr_conv2d_forward builds that image in its workspace on every call.
- *   rvsr_conv2d_pack_weights / rvsr_dcn_pack_weights write the image of one layer (forward: w_mode 0, data gradient: w_mode 1) to
+ *   rvsr_conv2d_pack_weights / rvsr_dcn_pack_weights write the image of one layer (forward: w_mode 0, data gradient: w_mode 1; w_mode 4:
+ *   the forward image of a 3x3 layer with Co > 32 in the f16 + fp8 format of rvsr_conv2d_forward's w_mode | 4, for stride-1 use only) to
  *   caller-owned memory of rvsr_conv2d_forward_workspace_bytes(C_in, 0, Co, ksize) /
  *   rvsr_modulated_deform_conv_forward_workspace_bytes(channels, channels_out) bytes and return that size (0 = bad argument);
  *   `desc` (NULL or 10 x long long, host; 20 x long long for rvsr_dcn_pack_weights) receives {weight, out, Co, C_in, taps, MP, CCG,

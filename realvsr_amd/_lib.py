@@ -108,11 +108,14 @@ def lib():
         if mode not in GEMM_MODES:
             raise RuntimeError("RVSR_GEMM must be one of %s, got %r" % (sorted(GEMM_MODES), mode))
         handle.rvsr_set_gemm_mode(GEMM_MODES[mode])
+        global _fmt_f16fp8
+        _fmt_f16fp8 = mode == 'f16fp8'
         _lib = handle
     return _lib
 
 
-GEMM_MODES = {'bf16x3': 0, 'f32': 1, 'bf16x2': 2, 'bf16': 3}
+GEMM_MODES = {'bf16x3': 0, 'f32': 1, 'bf16x2': 2, 'bf16': 3, 'f16fp8': 0}   # ('f16fp8': library mode 0 + the per-call format flag, below)
+_fmt_f16fp8 = False
 
 
 def set_gemm_mode(mode):
@@ -123,8 +126,19 @@ def set_gemm_mode(mode):
              pair -- ~2^-9 per product, i.e. the network with bf16-rounded weights evaluated on f32 activations;
     'bf16'   one term, both operands rounded to bf16 (the usual mixed-precision product).
     The reduced-term modes are opt-in speed modes of conv_fwd5 / conv_wgrad2 / the DCN kernels (every other kernel keeps three terms);
-    tests/test_gpu_modes.py holds them to the 1e-3 dB PSNR bound of the north star."""
+    tests/test_gpu_modes.py holds them to the 1e-3 dB PSNR bound of the north star.
+    'f16fp8' (round 5, opt-in, FORWARD convolutions only): everything as in 'bf16x3' except that the 3x3 / stride-1 forward convs with more
+             than 32 output channels form a product as a1*b1 in f16 + (a1*b2 + a2*b1) in fp8 e4m3 (a1 = f16(a), a2 = a - a1): 56 instead of
+             108 matrix instructions per 16-channel stage, ~1.2e-5 instead of 4.6e-6 per convolution.  It is a per-call
+             flag of rvsr_conv2d_forward (w_mode | 4) that realvsr_amd.functional sets while this mode is selected; data and weight
+             gradients, the DCN kernels and every other conv keep the three-term bf16 split."""
+    global _fmt_f16fp8
     lib().rvsr_set_gemm_mode(GEMM_MODES[mode])
+    _fmt_f16fp8 = mode == 'f16fp8'
+
+
+def fmt_f16fp8():
+    return _fmt_f16fp8
 
 
 def set_gemm_mode_thread(mode):
@@ -135,6 +149,8 @@ def set_gemm_mode_thread(mode):
 
 def get_gemm_mode():
     m = lib().rvsr_get_gemm_mode()
+    if m == 0 and _fmt_f16fp8:
+        return 'f16fp8'
     return [k for k, v in GEMM_MODES.items() if v == m][0]
 
 

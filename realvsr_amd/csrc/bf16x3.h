@@ -67,6 +67,8 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
 
 // ------------------------------------------------------------------------------------------
 // packed[mb][chunk][part][tap][oc][m][8]: part 0 = hi, 1 = lo; oc < 2*CCG octets of the chunk;
+// (mode | 0x100, CCG = 1: the f16 + fp8 format -- part 0 = the octets as f16, part 1 = [tap][kind][m][16 channels of the chunk] fp8 e4m3, kind 0 = f16(w),
+//  kind 1 = (w - f16(w)) * 2^12; conv_fwd5_kernel<.., NT = 4>)
 // m < MP rows of m-block mb.   mode 0: A[o][(tap,c)] = w[o][c][tap]  (w: [Co][Ctot][T])
 //                               mode 1: A[i][(tap,k)] = w[k][i][T-1-tap]  (w: [Ctot][Co][T])
 //                               mode 2 (dcn_fwd4_kernel; T = 1, CCG = 1, "chunk" = k-step j, oc = lane half h):
@@ -92,6 +94,34 @@ __device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, b
         const int chunk = (int)(r % nchunks);
         const int mb = (int)(r / nchunks);
         const int o = mb * MP + m;
+        if (mode & 0x100) {   // "f16 main term + fp8 cross terms" image (rvsr_conv2d_forward w_mode | 4): format flag in bit 8 of `mode`
+            // hi image: the octet's 8 channels as f16; lo image slot (tap, kind = oc, m): the chunk's 16 channels as fp8 e4m3 --
+            // kind 0: a1 = f16(w), kind 1: (w - a1) * 2^12 (the MFMA's block scale takes the 2^12 back)
+            typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+            typedef int i32x4p __attribute__((ext_vector_type(4)));
+            f16x8p h;
+            float q[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = chunk * 16 + j;
+                const float x = (o < Co && c < Ctot) ? w[((size_t)o * Ctot + c) * T + tap] : 0.f;
+                const float a1 = (float)(_Float16)x;
+                q[j] = oc ? (x - a1) * 4096.f : a1;
+                if ((j >> 3) == oc) h[j & 7] = (_Float16)x;
+            }
+            i32x4p f8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int wd = 0;
+                wd = __builtin_amdgcn_cvt_pk_fp8_f32(q[4 * k], q[4 * k + 1], wd, false);
+                wd = __builtin_amdgcn_cvt_pk_fp8_f32(q[4 * k + 2], q[4 * k + 3], wd, true);
+                f8[k] = wd;
+            }
+            const size_t blk = ((size_t)mb * nchunks + chunk) * 2, inner = ((size_t)tap * noct + oc) * MP + m, per = (size_t)T * noct * MP;
+            packed[blk * per + inner] = __builtin_bit_cast(bf16x8, h);
+            packed[(blk + 1) * per + inner] = __builtin_bit_cast(bf16x8, f8);
+            continue;
+        }
         const int unit = chunk * 2 + oc;                                   // (mode 2)
         const int cb = mode == 2 ? 8 * (unit / 9) : (chunk * noct + oc) * 8;
         float v[8];

@@ -486,6 +486,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fwd2_kernel(const ConvFwdPara
 // NT: terms of the bf16 product (rvsr_set_gemm_mode): 3 = hi*hi + hi*lo + lo*hi (f32-grade, the default); 2 = the weights' lo part is
 // dropped (W rounded to bf16, activations / gradients full: two MFMAs per product, the lo half of the weight image is neither loaded nor
 // published); 1 = plain bf16 operands (one MFMA, no lo image of the input tile either).  Accumulation is f32 in every mode.
+// NT = 4 is not a term count but the f16 + fp8 product FORMAT (ConvFwdParams.fmt; DESIGN.md 5h, experiments/f16fp8/README.md): a1 * b1 in f16 +
+// a1 * b2 + a2 * b1 in fp8 e4m3 with a1 = f16(a), a2 = a - a1 -- per tap four v_mfma_f32_32x32x16_f16, per pair of taps four
+// v_mfma_scale_f32_32x32x64_f8f6f4: 56 matrix instructions per stage instead of 108, ~1.2e-5 per 576-deep GEMM instead of 4.6e-6.
 template <int MT, bool ACT_IN, int VEC, bool WIDE = false, int NT = 3>
 __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p) {
     constexpr int KS = 3, T = 9, PAD = 1, NW = 8, TH = WIDE ? NW : 2 * NW, TW = WIDE ? 64 : 32, NTHR = NW * 64;
@@ -733,14 +736,45 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                     float x = ACT_IN ? vin[i][j][e] * (ain[i][j][e] > 0.f ? 1.f : va.slope) : vin[i][j][e];
                     v[j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & vm[j]);
                 }
-                bf16x8 h8, l8;
-                split8(v, h8, l8);
                 const int dst = it_dst[i] + e;
                 bool ok = dst >= 0;
                 if (VEC) {  // groups 0 and 9 straddle the tile's 34-pixel row
                     const int s = 4 * (tid % NG) - 3 + e;
                     ok = ok && s >= 0 && s < IW;
                 }
+                if (NT == 4) {
+                    // f16 + fp8 format (NT == 4): hi image = the octet as f16; lo image = [kind][position][16 channels] fp8 e4m3, kind 0: (v - f16(v)) * 2^12,
+                    // kind 1: f16(v) -- this octet's 8 bytes of each (the matrix instruction's block scales take the 2^12 back)
+                    typedef _Float16 f16x8c __attribute__((ext_vector_type(8)));
+                    typedef int i32x2c __attribute__((ext_vector_type(2)));
+                    f16x8c h;
+                    float r2[8], r1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        h[j] = (_Float16)v[j];
+                        r1[j] = (float)h[j];
+                        r2[j] = (v[j] - r1[j]) * 4096.f;
+                    }
+                    i32x2c q2, q1;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        int w2 = 0, w1 = 0;
+                        w2 = __builtin_amdgcn_cvt_pk_fp8_f32(r2[4 * k], r2[4 * k + 1], w2, false);
+                        w2 = __builtin_amdgcn_cvt_pk_fp8_f32(r2[4 * k + 2], r2[4 * k + 3], w2, true);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r1[4 * k], r1[4 * k + 1], w1, false);
+                        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r1[4 * k + 2], r1[4 * k + 3], w1, true);
+                        q2[k] = w2; q1[k] = w1;
+                    }
+                    const int pos = dst - it_oc[i] * NPOS;
+                    unsigned char* lo_b = reinterpret_cast<unsigned char*>(xs_lo);
+                    unsigned char* sink_b = reinterpret_cast<unsigned char*>(sink);
+                    *(ok ? xs_hi + dst : sink) = __builtin_bit_cast(bf16x8, h);
+                    *reinterpret_cast<i32x2c*>(ok ? lo_b + (size_t)pos * 16 + 8 * it_oc[i] : sink_b) = q2;
+                    *reinterpret_cast<i32x2c*>(ok ? lo_b + ((size_t)NPOS + pos) * 16 + 8 * it_oc[i] : sink_b) = q1;
+                    continue;
+                }
+                bf16x8 h8, l8;
+                split8(v, h8, l8);
                 bf16x8* const dh = ok ? xs_hi + dst : sink;
                 bf16x8* const dl = ok ? xs_lo + dst : sink;
                 *dh = h8;
@@ -833,6 +867,42 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 #ifdef RVSR_TIMELINE
             if (blockIdx.x == 77 && lane == 0 && q == Q - 6) rvsr_dbg[300 + wave * 12 + tap] = __builtin_amdgcn_s_memtime();
 #endif
+            if (NT == 4) {
+                // f16 + fp8 format (NT == 4): the cross terms a1 * b2 + a2 * b1 of TWO taps in one 64-deep fp8 instruction (lane half 0 holds the
+                // a1 / b2 * 2^12 pieces, half 1 the a2 * 2^12 / b1 pieces: the E8M0 block scale of a lane's 32 k undoes the 2^12), issued
+                // before the next fetch overwrites the previous tap's fragments; then the main term a1 * b1 in f16
+                typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+                typedef int i32x4m __attribute__((ext_vector_type(4)));
+                typedef int i32x8m __attribute__((ext_vector_type(8)));
+                const int sa = hi ? 127 - 12 : 127, sb = hi ? 127 : 127 - 12;
+                if (tap & 1) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const i32x8m pa = __builtin_shufflevector(__builtin_bit_cast(i32x4m, al[sl ^ 1][m]), __builtin_bit_cast(i32x4m, al[sl][m]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            const i32x8m pb = __builtin_shufflevector(__builtin_bit_cast(i32x4m, bl[sl ^ 1][n]), __builtin_bit_cast(i32x4m, bl[sl][n]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa, pb, acc[m][n], 0, 0, 0, sa, 0, sb);
+                        }
+                }
+                if (tap + 1 < T) fetch(tap + 1, sl ^ 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8m, ah[sl][m]), __builtin_bit_cast(f16x8m, bh[sl][n]), acc[m][n], 0, 0, 0);
+                if (tap == T - 1) {   // the ninth tap has no partner: the upper half of its K is zero on the weight side
+                    const i32x4m z = {0, 0, 0, 0};
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const i32x8m pa = __builtin_shufflevector(__builtin_bit_cast(i32x4m, al[sl][m]), z, 0, 1, 2, 3, 4, 5, 6, 7);
+                            const i32x8m pb = __builtin_shufflevector(__builtin_bit_cast(i32x4m, bl[sl][n]), __builtin_bit_cast(i32x4m, bl[sl][n]), 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa, pb, acc[m][n], 0, 0, 0, sa, 0, sb);
+                        }
+                }
+            } else {
             if (tap + 1 < ((ABL5 & 1) ? 2 : T)) fetch(tap + 1, sl ^ 1);   // (ABL5 & 1: fragments of taps 0 and 1 reused for taps 2-8)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -849,6 +919,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) acc[m][n] = mfma_bf16(al[sl][m], bh[sl][n], acc[m][n]);
+            }
             }
             // ---- this wave's own staging work, a slice per tap, in the shadow of the MFMAs above (a wave's own
             // VALU/LDS instructions fill its MFMA issue gaps; another wave's barely do):
@@ -914,6 +985,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd5_kernel(const ConvFwdParams p
 
 // ------------------------------------------------------------------------------------------
 // host side (called from conv_kernels.hip)
+// The f16 + fp8 product format (ConvFwdParams.fmt) exists in the 3x3 / stride-1 kernels with 64-row m-blocks, forward weights only
+static inline bool f16fp8_ok(int ksize, int stride, int mt, int w_mode) { return ksize == 3 && stride == 1 && mt == 2 && w_mode == 0; }
 static void fwd2_geom(int ksize, int Co, int Ctot, int& mt, int& ccg, int& nchunks, int& nmb) {
     // never more than 2 M tiles per workgroup: the MT = 4 instantiation keeps 128 accumulator registers live and
     // spills (130-190 VGPRs to scratch); two 64-row m-blocks re-stage the input tile but run spill-free
@@ -973,7 +1046,7 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
                                : (vec == 3 ? conv_fwd5_kernel<MT, false, 3> : vec == 2 ? conv_fwd5_kernel<MT, false, 2>
                                   : vec ? conv_fwd5_kernel<MT, false, 1> : conv_fwd5_kernel<MT, false, 0>);
     // reduced-term products (gemm modes 2 / 3): the 64-row m-block kernels on the vector-staged views; everything else keeps three terms
-    const int nt = (MT == 2 && vec != 0) ? rvsr_gemm_terms() : 3;
+    const int nt = (MT == 2 && vec != 0 && !p.fmt) ? rvsr_gemm_terms() : 3;
     if constexpr (MT == 2) {
 #define FWD5_NT(NTV)                                                                                                                   \
         k = va.act != nullptr ? (vec == 3 ? conv_fwd5_kernel<MT, true, 3, false, NTV> : vec == 2 ? conv_fwd5_kernel<MT, true, 2, false, NTV> \
@@ -982,6 +1055,14 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
                                                                                        : conv_fwd5_kernel<MT, false, 1, false, NTV>)
         if (nt == 2) { FWD5_NT(2); } else if (nt == 1) { FWD5_NT(1); }
 #undef FWD5_NT
+    }
+    if (p.fmt) {   // f16 + fp8 images: only the vector-staged kernels without act' read them
+        if constexpr (MT == 2) {
+            if (vec != 1 || va.act != nullptr) FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: the f16 + fp8 format needs a plain 16-byte-aligned input view with W %% 4 == 0 and no act' tensor");
+            k = conv_fwd5_kernel<MT, false, 1, false, 4>;
+        } else {
+            FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: the f16 + fp8 format needs more than 32 output channels");
+        }
     }
     // tile shape: 8 x 64 (256-byte output runs, 16-byte stores, plain vector-staged view) when it wastes no more pixels than 16 x 32
     int th = 16, tw = 32;
@@ -993,6 +1074,7 @@ static int launch_fwd5(const ConvFwdParams& p, hipStream_t st) {
         if (p.act == 3 && !(wide_ok && vec == 1 && p.vec4 && px_w <= px_n)) return RVSR_ERR_UNSUPPORTED;   // (mask epilogue: 8 x 64 tile only)
         if (wide_ok && vec == 1 && p.vec4 && px_w <= px_n) {
             k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true> : conv_fwd5_kernel<MT, false, 1, true>;
+            if (p.fmt) k = conv_fwd5_kernel<MT, false, 1, true, 4>;
             if (nt == 2) k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true, 2> : conv_fwd5_kernel<MT, false, 1, true, 2>;
             if (nt == 1) k = va.act != nullptr ? conv_fwd5_kernel<MT, true, 1, true, 1> : conv_fwd5_kernel<MT, false, 1, true, 1>;
             th = 8; tw = 64;
@@ -1024,9 +1106,11 @@ int rvsr_launch_conv_fwd2(ConvFwdParams p, int ksize, int stride, void* workspac
     }
     const int T = ksize * ksize;
     const size_t total = (size_t)nmb * nchunks * T * (2 * ccg) * (mt * 32);
+    if (p.fmt && (!f16fp8_ok(ksize, stride, mt, p.w_mode) || rvsr_gemm_mode_now() == 1))
+        FAIL(RVSR_ERR_UNSUPPORTED, "conv2d: the f16 + fp8 format (w_mode | 4) is for forward 3x3 / stride-1 convs with more than 32 output channels");
     if (!p.prepacked)
         hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.w, (bf16x8*)workspace, p.Co,
-                           Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode);
+                           Ctot, T, mt * 32, ccg, nchunks, nmb, p.w_mode | (p.fmt ? 0x100 : 0));
     p.wpack = workspace;
     p.swz = rvsr_swizzle_enabled();
     // (the 16-byte-store epilogues address one batch element of the output / residual with 32-bit byte offsets in a 2 GB buffer view)
@@ -1053,13 +1137,15 @@ extern "C" size_t rvsr_conv2d_pack_weights(const float* weight, int C_in, int Co
     fwd2_geom(ksize, Co, C_in, mt, ccg, nchunks, nmb);
     const size_t need = rvsr_conv_fwd2_workspace_bytes(ksize, Co, C_in);
     if (!weight || !out || out_bytes < need) return 0;
+    if ((w_mode & 4) && !f16fp8_ok(ksize, 1, mt, w_mode & 1)) return 0;   // (the caller vouches for stride 1)
+    const int fmtflag = (w_mode & 4) ? 0x100 : 0;
     const int T = ksize * ksize;
     const size_t total = (size_t)nmb * nchunks * T * (2 * ccg) * (mt * 32);
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, (bf16x8*)out, Co,
-                       C_in, T, mt * 32, ccg, nchunks, nmb, w_mode & 1);
+                       C_in, T, mt * 32, ccg, nchunks, nmb, (w_mode & 1) | fmtflag);
     if (desc) {
         desc[0] = (long long)(uintptr_t)weight; desc[1] = (long long)(uintptr_t)out;
-        desc[2] = Co; desc[3] = C_in; desc[4] = T; desc[5] = mt * 32; desc[6] = ccg; desc[7] = nchunks; desc[8] = nmb; desc[9] = w_mode & 1;
+        desc[2] = Co; desc[3] = C_in; desc[4] = T; desc[5] = mt * 32; desc[6] = ccg; desc[7] = nchunks; desc[8] = nmb; desc[9] = (w_mode & 1) | fmtflag;
     }
     return need;
 }

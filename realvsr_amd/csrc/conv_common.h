@@ -17,6 +17,7 @@ struct ConvFwdParams {
     int B, Co, Hout, Wout;
     int w_mode;
     int prepacked;      // `workspace` already holds the packed weight image of this call (rvsr_conv2d_pack_weights / _batched)
+    int fmt;            // 1: f16 + fp8 product format (w_mode | 4): forward 3x3 / stride-1 convs of the 64-row kernels only
     int act;
     float slope;
     int ps;

@@ -336,6 +336,7 @@ extern "C" int rvsr_conv2d_forward(const float* x1, int C1, const float* x2, int
     p.Wout = Wout;
     p.w_mode = w_mode & 1;
     p.prepacked = (w_mode >> 1) & 1;
+    p.fmt = (w_mode >> 2) & 1;
     p.act = act;
     p.slope = slope;
     p.ps = pixel_shuffle;

@@ -287,6 +287,9 @@ def _conv_fwd(L, x1, C1, x2, C2, xact, xact_slope, in_mode, Hs, Ws, weight, bias
     """rvsr_conv2d_forward with the weight image from the per-step cache when `wparam` (the nn.Parameter behind `weight`,
     default: none = per-call packing into the shared scratch) lives in FlatBuffers."""
     nbytes = L.rvsr_conv2d_forward_workspace_bytes(C1, C2, Co1 + Co2, k)
+    if (_lib.fmt_f16fp8() and k == 3 and stride == 1 and w_mode == 0 and Co1 + Co2 > 32 and not xact and in_mode == 0 and Ws % 4 == 0
+            and (C2 == 0 or C1 % 16 == 0) and ((getattr(x1, 'value', None) or 0) | (getattr(x2, 'value', None) or 0)) % 16 == 0):
+        w_mode |= 4     # 'f16fp8' mode: this forward conv in the f16 + fp8 product format (weight image and kernel; _lib.set_gemm_mode)
     buf = packed_weights.get(wparam, 'conv', C1 + C2, Co1 + Co2, k, w_mode, nbytes) if wparam is not None else None
     if buf is not None:
         ws, w_mode = buf, w_mode | 2

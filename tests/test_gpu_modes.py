@@ -129,7 +129,7 @@ def test_dcn_pack_backward(speed_mode):
     assert l2_err(got[0], ref[0]) > 1e-4   # (it is a reduced-term product)
 
 
-@pytest.mark.parametrize('mode', ['bf16x2', 'bf16'])
+@pytest.mark.parametrize('mode', ['bf16x2', 'bf16', 'f16fp8'])
 def test_config2_window_holds_the_north_star_psnr_bound(mode):
     """BASELINE config 2's window (EDVR-M nf64, 5 x 180 x 320, offsets rescaled to 1 px) in a speed mode against the CPU oracle."""
     import os
@@ -250,3 +250,57 @@ def test_dcn_shapes_in_the_speed_modes(shape, speed_mode):
     selection) in the speed modes, against the oracle at their tolerance."""
     from test_gpu_dcn import test_random_shapes_vs_oracle
     test_random_shapes_vs_oracle(shape, speed_mode)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# 'f16fp8' (round 5): the forward 3 x 3 / stride-1 convs with more than 32 output channels in the f16 + fp8 product format
+# (a1*b1 in f16 + (a1*b2 + a2*b1) in fp8 e4m3, a1 = f16(a), a2 = a - a1; DESIGN.md 5h), everything else as in the default mode.
+@pytest.fixture
+def f16fp8_mode():
+    from realvsr_amd import _lib
+    old = _lib.get_gemm_mode()
+    _lib.set_gemm_mode('f16fp8')
+    assert _lib.get_gemm_mode() == 'f16fp8'
+    yield 'f16fp8'
+    _lib.set_gemm_mode(old)
+    assert _lib.get_gemm_mode() == old
+
+
+def test_f16fp8_forward_error_and_scope():
+    """Where the format acts the forward error against f64 is ~1.2e-5 (default: ~4.6e-6; the two-term mode: 1.7e-3) -- above the default's, which
+    shows that the format ran, and below 2.5e-5; where it does not act (32 output channels, 1x1, stride 2, and every gradient of a conv
+    without activation) the results are those of the default mode bit for bit."""
+    from realvsr_amd import functional as RF, _lib
+    d = dev()
+    torch.manual_seed(11)
+    old = _lib.get_gemm_mode()
+    try:
+        for (C, Co, k, stride, H, W, acts) in [(64, 64, 3, 1, 64, 96, True), (128, 128, 3, 1, 40, 64, True), (48, 40, 3, 1, 37, 64, True),
+                                               (64, 32, 3, 1, 40, 64, False), (64, 64, 1, 1, 40, 64, False), (64, 64, 3, 2, 40, 64, False)]:
+            conv = nn.Conv2d(C, Co, k, stride, k // 2).to(d)
+            x = torch.randn(2, C, H, W, device=d, requires_grad=True)
+            ref = F.conv2d(x.detach().double(), conv.weight.double(), conv.bias.double(), stride=stride, padding=k // 2)
+            got = {}
+            for mode in ('bf16x3', 'f16fp8'):
+                _lib.set_gemm_mode(mode)
+                x.grad = None
+                conv.weight.grad = None
+                y = RF.conv2d(x, conv, RF.ACT_NONE)
+                y.backward(torch.ones_like(y))
+                got[mode] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone())
+            e3, e8 = l2_err(got['bf16x3'][0], ref), l2_err(got['f16fp8'][0], ref)
+            print((C, Co, k, stride, H, W), 'forward l2 error against f64: default %.2e, f16fp8 %.2e' % (e3, e8))
+            if acts:
+                assert 7e-6 < e8 < 2.5e-5 and e3 < 7e-6, (e3, e8)
+            else:
+                assert torch.equal(got['bf16x3'][0], got['f16fp8'][0])
+            assert torch.equal(got['bf16x3'][1], got['f16fp8'][1]) and torch.equal(got['bf16x3'][2], got['f16fp8'][2])   # gradients: the default kernels
+    finally:
+        _lib.set_gemm_mode(old)
+
+
+@pytest.mark.parametrize('case', _speed_mode_conv_cases(), ids=lambda c: '-'.join(str(v) for v in c))
+def test_conv_shapes_in_the_f16fp8_mode(case, f16fp8_mode):
+    """The conv shape sweep (ragged tiles, concat inputs, residuals, PixelShuffle stores, widths on and off the vector path) in the 'f16fp8' mode."""
+    from test_gpu_conv import test_conv_block_forward_backward
+    test_conv_block_forward_backward(case, 'f16fp8')
