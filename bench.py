@@ -679,6 +679,57 @@ def infer_line(a, T=10, offset_px=None):
     return res
 
 
+def dry_run_plan(args):
+    """`--dry-run` without a launcher: everything the N-rank run is going to do that can be known on the host -- the per-rank shard of the
+    global batch (the reference: batch_size // world_size, codes/data/__init__.py:10-15; DistIterSampler's contiguous per-rank ranges,
+    codes/data/data_sampler.py:46-59), the bucket table of the gradient all-reduce built by the SAME code the run uses
+    (realvsr_amd.dist.BucketedGradAllReduce on the architecture's parameters), the ring time of each bucket on one xGMI link, and the memory
+    plan (4 flat buffers + the last measured single-GPU peak of this configuration).  Needs no GPU."""
+    from realvsr_amd.archs.EDVR_arch import EDVR
+    from realvsr_amd.dist import BucketedGradAllReduce, shard_range
+    from realvsr_amd.optim import FlatBuffers
+    world, B = args.gpus, args.batch
+    torch.manual_seed(0)
+    net = EDVR(nf=args.nf, nc=3, nframes=args.nframes, groups=8, front_RBs=5, back_RBs=args.back_rbs, w_TSA=True)
+    names = {p: n for n, p in net.named_parameters()}
+    buffers = FlatBuffers([list(net.parameters())])
+    bucket_mb = float(os.environ.get('RVSR_BUCKET_MB', '4'))
+    red = BucketedGradAllReduce(None, bucket_mb=bucket_mb, buffers=buffers, broadcast=False)
+    link_gbs = 153.0   # one xGMI link direction (MI355X_MICROARCH / SURVEY.md section 5): a ring all-reduce is per-link bound
+    table = []
+    for i, (s, e) in enumerate(red.buckets):
+        members = [q for q in red.params if red._bucket_of[q] == i]
+        table.append({'bucket': i, 'offset_elems': s, 'bytes': 4 * (e - s), 'params': len(members), 'first': names[members[0]],
+                      'last': names[members[-1]],
+                      'ring_ms_on_one_link': round(2.0 * (world - 1) / max(world, 1) * 4 * (e - s) / (link_gbs * 1e9) * 1e3, 4)})
+    measured = None
+    for r in range(9, 0, -1):   # the newest committed driver-style line that carries this configuration's peak
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r%02d_bench_default.json' % r)) as f:
+                c3 = json.load(f).get('extra', {}).get('config3', {})
+            if args.nf == 128 and args.nframes == 7 and c3.get('peak_mem_GB'):
+                measured = {'peak_mem_GB': c3['peak_mem_GB'], 'batch': 16, 'source': 'profiles/r%02d_bench_default.json extra.config3' % r}
+                break
+        except (OSError, ValueError):
+            continue
+    flat_gb = 4 * 4 * buffers.numel / 2 ** 30
+    mem = {'flat_buffers_GB': round(flat_gb, 3), 'hbm_per_gpu_GB': 288,
+           'note': 'parameters, gradients and both Adam moments are four flat f32 buffers; activations dominate and scale with the per-GPU batch'}
+    if measured is not None:
+        est = measured['peak_mem_GB'] * B / measured['batch']
+        mem.update(measured_single_gpu=measured, estimate_GB_at_this_per_gpu_batch=round(est, 1), headroom_GB=round(288 - est, 1))
+    return {'dry_run': True, 'config': args.config, 'world': world, 'per_gpu_batch': B, 'global_batch': world * B,
+            'arch': 'EDVR nf%d, %d frames, back_RBs %d, TSA' % (args.nf, args.nframes, args.back_rbs),
+            'shards': [{'rank': r, 'windows': list(shard_range(world * B, r, world))} for r in range(world)],
+            'parameters': sum(p.numel() for p in net.parameters()), 'flat_elems_incl_alignment': buffers.numel,
+            'gradient_bytes': 4 * buffers.numel, 'bucket_mb': bucket_mb, 'buckets': table,
+            'collectives_per_step': len(table),
+            'ring_ms_total_on_one_link': round(sum(t['ring_ms_on_one_link'] for t in table), 4),
+            'memory': mem, 'backend': os.environ.get('RVSR_BENCH_BACKEND', 'nccl'),
+            'launch': 'python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py '
+                      '--config %d --gpus %d' % (world, args.config, world)}
+
+
 def relaunch(args):
     """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves."""
     s = socket.socket()
@@ -726,6 +777,9 @@ def main():
     if args.offset_px is not None and args.offset_px <= 0:
         args.offset_px = None
 
+    if args.dry_run and 'WORLD_SIZE' not in os.environ:
+        print(json.dumps(dry_run_plan(args)), flush=True)   # host-only: works without a GPU and without a launcher
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))

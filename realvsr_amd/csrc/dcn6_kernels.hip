@@ -829,7 +829,10 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         __syncthreads();   // (every wave is done with the x tile)
     }
 
-    // ---- partial of this (stream, unit): sum of the 4 waves (rows), fixed order, through LDS
+    // ---- partial of this (stream, unit): sum of the waves (rows), fixed order, through LDS.  The last tile asked for itself again: that
+    // LDS-DMA (and the x / offset loads) may still be in flight, hipcc does not count LDS-DMA, a barrier does not drain VMEM -- and `red` below
+    // aliases the operand slots (rows of waves 6-7 overlap wave 0's set-0 slot at TH = 8): drain before the barrier (round-5 advisor finding).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
         float* red = reinterpret_cast<float*>(smem_raw);   // [TH waves][16 registers][64 lanes] = 16 / 32 KB (x tile + operand slots: free now)
@@ -861,17 +864,23 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
     }
 }
 
-// streams (= partials) of a launch; 0: geometry not covered
-static int bwdw6_streams(int Co, int C, int* nmb_out, int* xcd_out) {
+// streams (= partials) of a launch with `wpc` workgroups per CU; 0: geometry not covered
+static int bwdw6_streams(int Co, int C, int wpc, int* nmb_out, int* xcd_out) {
     const int nchunks = C / 8, nmb = (Co + 63) / 64, U = nchunks * nmb;
     if (U <= 0 || U > 256) return 0;
     if (nmb_out) *nmb_out = nmb;
-    // ONE workgroup of 8 waves per CU (two of 4 waves gave run-to-run different results: profiles/r05_notes.md)
     if (xcd_out) *xcd_out = 32 % U == 0 ? 1 : 0;
-    return 256 / U > 0 ? 256 / U : 1;
+    return 256 * wpc / U > 0 ? 256 * wpc / U : 1;
+}
+// Developer switch RVSR_BWDW6_WG=2: two workgroups of four waves per CU (4-row tiles, 2 px window) instead of one of eight (8-row tiles, 4 px
+// window) -- the configuration whose run-to-run differences round 5 could not explain; kept selectable so that the determinism test covers it
+// (profiles/r06_notes.md).
+static int bwdw6_wpc() {
+    static const int v = [] { const char* e = getenv("RVSR_BWDW6_WG"); return e && atoi(e) == 2 ? 2 : 1; }();
+    return v;
 }
 size_t rvsr_dcn_bwdw6_workspace_bytes(int Co, int C) {
-    const int ns = bwdw6_streams(Co, C, nullptr, nullptr);
+    const int ns = bwdw6_streams(Co, C, 2, nullptr, nullptr);   // (sized for either schedule)
     return (size_t)ns * ((size_t)Co * C * 9 + Co) * sizeof(float) + 256;
 }
 // the operand buffer dcn_bwdin6 writes for dcn_bwdw6: one 16-byte vector per (row, x tile, 32 output channels, k-step, hi / lo, lane)
@@ -879,18 +888,9 @@ size_t rvsr_dcn_bwd6_agt_bytes(int B, int Co, int Ho, int Wo) {
     return (size_t)B * (((Ho + 7) / 8) * 8) * ((Wo + 31) / 32) * (size_t)(2 * ((Co + 63) / 64)) * 4 * 64 * 16;
 }
 
-// gw / gb are ACCUMULATED into (the reference's convention, cpp:659-671).  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdw4.
-int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st) {
-    if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128 || agt == nullptr) return RVSR_ERR_UNSUPPORTED;
-    int nmb = 0, xcd = 0;
-    const int ns = bwdw6_streams(d.Co, d.C, &nmb, &xcd);
-    if (ns <= 0 || !workspace || workspace_bytes < rvsr_dcn_bwdw6_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
-    // 32-bit byte offsets into one batch element's planes
-    const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)d.C ? (size_t)(d.C / d.cpg) * 18 : (size_t)d.C;
-    if (planes * (size_t)d.H * d.W * sizeof(float) >= ((size_t)1 << 31) || planes * (size_t)d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31) ||
-        (size_t)64 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
-        return RVSR_ERR_UNSUPPORTED;
-    constexpr int R = 4, TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
+template <int R, int TH>
+static int launch_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* gb, void* workspace, int ns, int nmb, int xcd, hipStream_t st) {
+    constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
     const size_t lds = (size_t)NPOS * 32 + (size_t)2 * TH * 8 * 64 * 16;
     DcnBwdW6Params p;
     p.d = d; p.agt = (const bf16x8*)agt; p.agt_nmb32 = 2 * nmb; p.agt_rows = ((d.Ho + 7) / 8) * 8;
@@ -907,4 +907,20 @@ int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* g
     if (e != hipSuccess) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdw6 launch: %s", hipGetErrorString(e));
     rvsr_launch_reduce(p.part, ns, nw, gw, 1, st, p.bpart, (size_t)d.Co, gb);
     return RVSR_OK;
+}
+
+// gw / gb are ACCUMULATED into (the reference's convention, cpp:659-671).  RVSR_ERR_UNSUPPORTED: the caller falls back to dcn_bwdw4.
+int rvsr_launch_dcn_bwdw6(const DcnGeom& d, const void* agt, float* gw, float* gb, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (d.cpg % 8 != 0 || d.C % 8 != 0 || d.stride != 1 || d.dil != 1 || d.Co > 128 || agt == nullptr) return RVSR_ERR_UNSUPPORTED;
+    int nmb = 0, xcd = 0;
+    const int wpc = bwdw6_wpc();
+    const int ns = bwdw6_streams(d.Co, d.C, wpc, &nmb, &xcd);
+    if (ns <= 0 || !workspace || workspace_bytes < rvsr_dcn_bwdw6_workspace_bytes(d.Co, d.C)) return RVSR_ERR_UNSUPPORTED;
+    // 32-bit byte offsets into one batch element's planes
+    const size_t planes = (size_t)(d.C / d.cpg) * 18 > (size_t)d.C ? (size_t)(d.C / d.cpg) * 18 : (size_t)d.C;
+    if (planes * (size_t)d.H * d.W * sizeof(float) >= ((size_t)1 << 31) || planes * (size_t)d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31) ||
+        (size_t)64 * d.Ho * d.Wo * sizeof(float) >= ((size_t)1 << 31))
+        return RVSR_ERR_UNSUPPORTED;
+    if (wpc == 2) return launch_bwdw6<2, 4>(d, agt, gw, gb, workspace, ns, nmb, xcd, st);
+    return launch_bwdw6<4, 8>(d, agt, gw, gb, workspace, ns, nmb, xcd, st);
 }

@@ -120,6 +120,72 @@ def test_identities(gemm_mode):
     check('far offsets == bias', out, b.view(1, -1, 1, 1).expand(2, 16, 10, 34), 0.0)
 
 
+# ---- oracle-independent pin of the HIP operator (round 6): spatially constant offsets, different per (deformable group, tap), per-pixel random
+# mask: the operator is then a sum of zero-filled shifts and 1 x 1 convolutions (tests/dcn_composition.py: torch slicing + F.conv2d, float64
+# autograd; no code shared with oracle/).  Pins the offset / mask channel orders, c // cpg, bilinear weights and the zero-outside rule of the
+# forward and of all five gradients (grad_offset as per-(group, tap) sums) -- see tests/test_oracle_dcn.py for the same check on the oracle.
+COMPOSITION_CASES = [
+    # B, C, Co, dg, H, W, seed
+    (2, 64, 64, 8, 20, 36, 21),     # cpg 8: dcn_fwd3 / dcn_bwdin6 / dcn_bwdw6
+    (1, 128, 64, 8, 12, 40, 22),    # cpg 16 (two chunks per deformable group)
+    (2, 16, 12, 4, 7, 9, 23),       # cpg 4 (two groups per chunk): the fifth-generation backward
+    (1, 8, 6, 1, 9, 33, 24),        # one deformable group
+]
+
+
+def _composition(case, kind, dtype, tol, tol_g):
+    import dcn_composition as DC
+    from realvsr_amd.archs.dcn import modulated_deform_conv
+    B, C, Co, dg, H, W, seed = case
+    x, dyx, mask, w, b, gout = DC.make_case(B, C, Co, dg, H, W, seed, dtype=dtype, kind=kind)
+    ref_out, (gx, gdyx, gm, gw, gb) = DC.composition_reference(x, dyx, mask, w, b, gout, dg)
+    d = dev()
+    leaves = [t.to(d).requires_grad_(True) for t in (x, DC.offset_field(dyx, B, H, W), mask, w, b)]
+    out = modulated_deform_conv(*leaves, 1, 1, 1, 1, dg)
+    out.backward(gout.to(d))
+    torch.cuda.synchronize()
+    tag = '%s %s ' % ('-'.join(str(v) for v in case[:6]), kind)
+    check(tag + 'out', out, ref_out, tol)
+    check(tag + 'grad_input', leaves[0].grad, gx, tol_g)
+    ok = DC.offset_grad_comparable(dyx)[:, :, None].double()
+    check(tag + 'grad_offset (pixel sums)', DC.offset_grad_sums(leaves[1].grad.cpu(), dg) * ok, gdyx * ok, 4 * tol_g)
+    check(tag + 'grad_mask', leaves[2].grad, gm, tol_g)
+    check(tag + 'grad_weight', leaves[3].grad, gw, tol_g)
+    check(tag + 'grad_bias', leaves[4].grad, gb, tol_g)
+
+
+@pytest.mark.parametrize('case', COMPOSITION_CASES, ids=lambda s: '-'.join(str(v) for v in s))
+def test_constant_offset_composition(case, gemm_mode):
+    tol = 2e-5 if gemm_mode == 'f32' else 1e-4
+    for kind in ('mixed', 'fractional', 'integer'):
+        _composition(case, kind, torch.float32, tol, max(TOL_G, tol))
+
+
+@pytest.mark.parametrize('case', COMPOSITION_CASES[2:], ids=lambda s: '-'.join(str(v) for v in s))
+def test_constant_offset_composition_f64_general_path(case):
+    """float64 tensors take the operator's general path (csrc/dcn_generic.hip): agreement to double precision."""
+    for kind in ('mixed', 'integer'):
+        _composition(case, kind, torch.float64, 1e-11, 1e-11)
+
+
+# ---- run-to-run determinism of everything but grad_input (round 6; the weight gradient comes from dcn_bwdw6: per-stream partials reduced in a fixed order)
+def test_dcn_weight_grad_is_deterministic():
+    import determinism_check as DET
+    for case in DET.CASES:
+        bad = DET.run_case(case, repeats=20)
+        assert not bad, (case, bad[:8])
+
+
+def test_dcn_weight_grad_is_deterministic_two_workgroups_per_cu():
+    """dcn_bwdw6 as two 4-wave workgroups per CU (RVSR_BWDW6_WG=2, read once per process): the schedule round 5 could not make reproducible."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, 'determinism_check.py')], env=dict(os.environ, RVSR_BWDW6_WG='2'),
+                         capture_output=True, text=True, timeout=900)
+    print(out.stdout[-1500:])
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 def test_pack_fixture(gemm_mode):
     """ModulatedDeformConvPack (fused conv_offset_mask + DCN) vs the reference wiring fixture.
     The offsets come out of a conv block, so in bf16x3 mode they carry ~1e-5 px of noise."""

@@ -144,3 +144,40 @@ def test_generic_geometry_zero_offsets_is_grouped_conv2d_and_f64_finite_differen
     def fn(x_, o_, m_, w_, b_):
         return modulated_deform_conv(x_, o_, m_, w_, b_, stride, pad, dil, groups, dg)
     assert torch.autograd.gradcheck(fn, leaves, eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
+# ---- an oracle-INDEPENDENT pin (round 6): spatially constant offsets make the operator a sum of zero-filled shifts and 1 x 1 convolutions
+# (tests/dcn_composition.py: torch slicing + F.conv2d only, no code shared with the oracle).  It pins what the identities above cannot
+# see with their uniform masks and group-independent offsets: the mask channel order g*K + k, the offset channel order g*2K + 2k (+1),
+# the channel -> deformable-group map c // cpg, bilinear weights, the zero-outside rule incl. the (-1, 0) / (H - 1, H) strips -- for the
+# forward and, through autograd on the construction, for all five gradients (grad_offset as per-(group, tap) sums over the pixels).
+def _composition_case(case, kind, dtype, tol):
+    import dcn_composition as DC
+    B, C, Co, dg, H, W, seed = case
+    x, dyx, mask, w, b, gout = DC.make_case(B, C, Co, dg, H, W, seed, dtype=dtype, kind=kind)
+    ref_out, (gx, gdyx, gm, gw, gb) = DC.composition_reference(x, dyx, mask, w, b, gout, dg)
+    leaves = [t.clone().requires_grad_(True) for t in (x, DC.offset_field(dyx, B, H, W), mask, w, b)]
+    out = modulated_deform_conv(*leaves, 1, 1, 1, 1, dg)
+    out.backward(gout)
+    assert rel_err(out, ref_out) < tol, 'out'
+    assert rel_err(leaves[0].grad, gx) < tol, 'grad_input'
+    ok = DC.offset_grad_comparable(dyx)[:, :, None].to(gdyx.dtype)   # (all but taps that sit exactly on the -1 boundary)
+    assert rel_err(DC.offset_grad_sums(leaves[1].grad, dg) * ok, gdyx * ok) < 10 * tol, 'grad_offset (summed over pixels)'
+    assert rel_err(leaves[2].grad, gm) < tol, 'grad_mask'
+    assert rel_err(leaves[3].grad, gw) < tol, 'grad_weight'
+    assert rel_err(leaves[4].grad, gb) < tol, 'grad_bias'
+
+
+COMPOSITION_CASES = [(2, 8, 6, 2, 6, 7, 11), (1, 12, 5, 3, 5, 9, 12), (2, 16, 8, 8, 7, 6, 13), (1, 6, 4, 1, 8, 5, 14)]
+
+
+def test_constant_offset_composition_f64():
+    for case in COMPOSITION_CASES:
+        for kind in ('mixed', 'fractional', 'integer'):
+            _composition_case(case, kind, torch.float64, 1e-12)
+
+
+def test_constant_offset_composition_f32():
+    for case in COMPOSITION_CASES:
+        for kind in ('mixed', 'integer'):
+            _composition_case(case, kind, torch.float32, 2e-6)
