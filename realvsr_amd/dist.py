@@ -97,7 +97,11 @@ class BucketedGradAllReduce:
         self._next = 0
         self._works = []
 
-    def _issue_ready(self):
+    def _issue_ready(self, from_hook=False):
+        if from_hook and _DIST_CHECK:
+            # developer check mode: no collective leaves before finish() has compared the ranks' gradient sets -- ranks that disagree have
+            # issued different numbers of bucket collectives by then, and the check's own all_reduce would pair up with one of those
+            return
         while self._next < len(self.buckets) and self._pending[self._next] <= 0:
             s, e = self.buckets[self._next]
             self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -106,7 +110,7 @@ class BucketedGradAllReduce:
     def _hook(self, p):
         self.buffers.rebind(p)   # (a gradient adopted from a plain torch module lives elsewhere: copy it into the bucket)
         self._pending[self._bucket_of[p]] -= 1
-        self._issue_ready()
+        self._issue_ready(from_hook=True)
 
     def finish(self):
         """Wait for the in-flight buckets and turn the sums into means. Call before optimizer.step()."""
