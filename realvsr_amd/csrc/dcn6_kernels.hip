@@ -21,6 +21,16 @@
 // launch against 7.3 for the pair: profiles/r05_notes.md.)
 #include "dcn_tile.h"
 
+#ifdef RVSR_TIMELINE_DCN6   // s_memtime stamps of one wave of one workgroup (tools/dcn6_timeline.py); [0, 128): dcn_bwdin6, [128, 256): dcn_bwdw6
+__device__ unsigned long long rvsr_dbg_dcn6[256];
+extern "C" int rvsr_debug_read_dcn6(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rvsr_dbg_dcn6), sizeof(unsigned long long) * 256); }
+#define TS6(i) do { if (blockIdx.x == 77 && blockIdx.z == 1 && threadIdx.x == 192) rvsr_dbg_dcn6[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TW6(i) do { if (blockIdx.x == 77 && threadIdx.x == 192) rvsr_dbg_dcn6[128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS6(i) do {} while (0)
+#define TW6(i) do {} while (0)
+#endif
+
 // Lane iteration `it` (0..4) of lane half h works on tap (half 0, half 1): (0, 3), (1, 6), (4, 7), (2, 5), (8, none).  The two taps of an
 // iteration sit in DIFFERENT kernel rows: the halves' cells of one ds_add_u32 are then a window row (+-) apart and never the same cell.
 // (First version: (0, 2), (1, 3), (4, 6), (5, 7) -- same row, two columns apart: lane (px + 2, half 0) and lane (px, half 1) hit the same
@@ -162,9 +172,19 @@ __device__ __forceinline__ void bwd6_emit_agt(bf16x8* dst, int nmb32, const bf16
 }
 
 // TERMS: terms of the bf16 product W^T * gOut (rvsr_common.h: gemm modes): 3 = hi*hi + hi*lo + lo*hi; 2 = without the weights' lo part;
-// 1 = hi*hi.  WPS: workgroups the launch bounds promise per CU.
-template <int NK, int R, int TERMS, int WPS>
-__global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Params p, const bf16x8* __restrict__ wpack) {
+// 1 = hi*hi.  WPS: waves per SIMD the launch bounds promise (2 = one 8-wave workgroup per CU).
+#ifndef RVSR_BWDIN6_G2
+#define RVSR_BWDIN6_G2 1      // scratch builds: 0 = one grad_input window, flushed between the barriers (the round-5 structure)
+#endif
+#ifndef RVSR_BWDIN6_LBMUL
+#define RVSR_BWDIN6_LBMUL 1   // scratch builds: 2 = hold the kernel to the 128 registers that two 8-wave workgroups per CU need: 53-69 spilled
+#endif                        // registers, 6.1 instead of 4.4 ms per L1 launch (round 5 read the bound's second argument as workgroups per CU; it
+                              // is waves per SIMD -- the kernel has always run ONE workgroup per CU; profiles/r06_notes.md)
+// W2: two weight buffers in LDS (the DMA of chunk c + 1 is issued at the top of chunk c's iterations instead of after them).
+// G2: two grad_input windows in LDS: chunk c scatters into one while the other -- chunk c - 1's -- is flushed a few rows per lane iteration
+// of chunk c, inside the iterations' own stalls, instead of as a phase of its own between two barriers (round 6).
+template <int NK, int R, int TERMS, int WPS, bool W2, bool G2>
+__global__ __launch_bounds__(512, WPS * RVSR_BWDIN6_LBMUL) void dcn_bwdin6_kernel(const DcnBwdIn6Params p, const bf16x8* __restrict__ wpack) {
     constexpr int TH = 8, NT = TH * 64;
     constexpr int TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
     constexpr int WBLK = 2 * (2 * NK) * 32;                        // vectors per (chunk, M tile): hi + lo
@@ -173,9 +193,9 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
     static_assert((3 * WBLK) % 64 == 0, "whole waves of weight vectors");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* xt = reinterpret_cast<float4*>(smem_raw);              // [2 quads][NPOS], zero outside the image
-    int* gwin = reinterpret_cast<int*>(xt + 2 * NPOS);             // [8 channels][NPOS]: the grad_input tile of this chunk, fixed point
-    bf16x8* wsb = reinterpret_cast<bf16x8*>(gwin + 8 * NPOS);      // [3][WBLK]
-    float* gn_red = reinterpret_cast<float*>(wsb + 3 * WBLK);      // [8 waves]: largest ||gOut[:, px]||^2 of the wave's row
+    int* gwin0 = reinterpret_cast<int*>(xt + 2 * NPOS);            // [G2 ? 2 : 1][8 channels][NPOS]: the grad_input tile of a chunk, fixed point
+    bf16x8* wsb = reinterpret_cast<bf16x8*>(gwin0 + (G2 ? 2 : 1) * 8 * NPOS);   // [W2 ? 2 : 1][3][WBLK]
+    float* gn_red = reinterpret_cast<float*>(wsb + (W2 ? 2 : 1) * 3 * WBLK);   // [8 waves]: largest ||gOut[:, px]||^2 of the wave's row
     if (dcn_halo_not_selected(p.sel)) return;   // (uniform) not the halo the offsets of this call ask for
     const DcnGeom& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
         for (int sft = 16; sft > 0; sft >>= 1) gsq = fmaxf(gsq, __shfl_xor(gsq, sft));
         if (lane == 0) gn_red[wave] = gsq;
     }
-    for (int e = tid; e < 8 * NPOS; e += NT) gwin[e] = 0;
+    for (int e = tid; e < (G2 ? 2 : 1) * 8 * NPOS; e += NT) gwin0[e] = 0;
     if (p.agt != nullptr)   // (uniform) this row's gOut as the weight-gradient kernel wants it (rows beyond Ho: zeros, the buffer covers the tile)
         bwd6_emit_agt<NK>(p.agt + (((size_t)b * p.agt_rows + oy) * d.ntx + tx) * (size_t)(p.agt_nmb32 * 4 * 64), p.agt_nmb32, gh, gl, lane);
 
@@ -247,43 +267,115 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
     float o_dy[5], o_dx[5], o_m[5];
     float xv[NXI][4];
     // requests of a chunk: (dy, dx, mask) of this lane's pixel at its five taps (15 loads), the weight blocks (LDS-DMA: lane l of a wave
-    // lands at M0 + 16 l, no registers), the x tile (registers; committed to LDS once the previous chunk's iterations are done)
-    auto request = [&](int chunk) {
-        const int c0 = chunk * 8, g = c0 / d.cpg;
+    // lands at M0 + 16 l, no registers), the x tile (registers; committed to LDS at the top of the chunk).  Round 6: after the first chunk
+    // they are issued a slice per lane iteration of the PREVIOUS chunk -- the triple of iteration `it` into the registers that iteration has
+    // just read, x item `it` into the registers the chunk's commit has freed -- instead of as one burst between the iterations and the flush:
+    // 34 vector-memory instructions in a row took 3 K of a chunk's 31 K cycles to issue (timeline in profiles/r06_notes.md).
+    auto request_offsets = [&](int it, int chunk) {
+        const int g = (chunk * 8) / d.cpg;
         const unsigned ob = (unsigned)(g * 18) * pl4, mb_ = (unsigned)(g * 9) * pl4;
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
-            const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
-            o_dy[it] = buf_load(off_rs, pix4 + 2u * tp, ob);
-            o_dx[it] = buf_load(off_rs, pix4 + 2u * tp, ob + pl4);
-            o_m[it] = buf_load(msk_rs, pix4 + tp, mb_);
-        }
+        const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : t0;   // (it == 4, half 1: no tap; reads tap 8, unused)
+        const unsigned tp = (unsigned)(hi ? t1 : t0) * pl4;
+        o_dy[it] = buf_load(off_rs, pix4 + 2u * tp, ob);
+        o_dx[it] = buf_load(off_rs, pix4 + 2u * tp, ob + pl4);
+        o_m[it] = buf_load(msk_rs, pix4 + tp, mb_);
+    };
+    auto request_weights = [&](int chunk, bf16x8* dst) {
         const bf16x8* src = wpack + (size_t)chunk * 3 * WBLK;
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int e = tid + i * NT;
             if (e - lane + 63 < 3 * WBLK)   // (wave-uniform)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e),
-                                                 (__attribute__((address_space(3))) void*)(wsb + e), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + e), 16, 0, 0);
         }
-#pragma unroll
-        for (int k = 0; k < NXI; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xoff[k], (unsigned)(c0 + e) * HW4);   // (C % 8 == 0)
     };
-    request(0);
+    auto request_x_item = [&](int k, int chunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xoff[k], (unsigned)(chunk * 8 + e) * HW4);   // (C % 8 == 0)
+    };
+#pragma unroll
+    for (int it = 0; it < 5; ++it) request_offsets(it, 0);
+    request_weights(0, wsb);
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) request_x_item(k, 0);
+    TS6(0);
+
+    // ---- flush of window rows [r0, r1) of the chunk at channel cf0: wave w owns channel cf0 + w; one global atomic per touched cell inside the
+    // image (the halos of neighbouring workgroups overlap), cell back to zero for its next use.  Round 6: a lane owns a window COLUMN and walks
+    // the rows four at a time -- no division per cell, the row test is scalar, the column test and the image offset are per-kernel constants
+    // (the round-5 form, four consecutive cells per lane, spent ~12 vector instructions per cell: a third of the kernel's vector work).
+    static_assert(TC <= 64, "one lane per window column");
+    const int fl_xx = tx0 + lane;
+    const bool fl_col_ok = lane < TC && fl_xx >= 0 && fl_xx < d.W;
+    const unsigned fl_col4 = 4u * (unsigned)(ty0 * d.W + fl_xx);   // (wraps for rows above the image: only used where the row test passed)
+    auto flush_rows = [&](int* win, int cf0, float inv_s, int r0, int r1) {
+        if (RVSR_ABL6 & 2) return;
+        const unsigned cpl = (unsigned)(cf0 + wave) * HW4;
+        int* gc = win + wave * NPOS + lane;
+        const bool ok = fl_col_ok && cf0 + wave < d.C;
+        if (lane < TC) {
+#pragma unroll 1
+            for (int r = r0; r < r1; r += 4) {
+                int v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = r + j < r1 ? gc[(r + j) * TC] : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int yy = ty0 + r + j;   // (uniform)
+                    if (v[j] != 0) {
+                        gc[(r + j) * TC] = 0;
+                        if (ok && yy >= 0 && yy < d.H)
+                            buf_atomic_add(gx_rs, fl_col4 + 4u * (unsigned)((r + j) * d.W), cpl, (float)v[j] * inv_s);
+                    }
+                }
+            }
+        }
+    };
+    constexpr int FRB = (TR + 4) / 5;   // window rows flushed per lane iteration (G2)
+    float invS_prev = 0.f;
+    // G2: the rows of one lane iteration in two halves -- the LDS reads at the top of the iteration (in front of its own atomics: read behind them
+    // they waited for the whole burst to drain), the atomics / re-zeroing at its end
+    auto flush_read = [&](const int* win, int r0, int (&v)[FRB]) {
+        const int* gc = win + wave * NPOS + (lane < TC ? lane : 0);
+#pragma unroll
+        for (int j = 0; j < FRB; ++j) v[j] = r0 + j < TR ? gc[(r0 + j) * TC] : 0;
+    };
+    auto flush_commit = [&](int* win, int cf0, float inv_s, int r0, const int (&v)[FRB]) {
+        if (RVSR_ABL6 & 2) return;
+        const unsigned cpl = (unsigned)(cf0 + wave) * HW4;
+        int* gc = win + wave * NPOS + lane;
+        const bool ok = fl_col_ok && cf0 + wave < d.C;
+#pragma unroll
+        for (int j = 0; j < FRB; ++j) {
+            const int yy = ty0 + r0 + j;   // (uniform)
+            if (lane < TC && v[j] != 0) {
+                gc[(r0 + j) * TC] = 0;
+                if (ok && yy >= 0 && yy < d.H)
+                    buf_atomic_add(gx_rs, fl_col4 + 4u * (unsigned)((r0 + j) * d.W), cpl, (float)v[j] * inv_s);
+            }
+        }
+    };
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int c0 = chunk * 8;
         const int g = c0 / d.cpg;
+        int* const gwin = gwin0 + (G2 ? (chunk & 1) * 8 * NPOS : 0);
+        int* const gwin_prev = gwin0 + (G2 ? ((chunk + 1) & 1) * 8 * NPOS : 0);
+        if (chunk < 4) TS6(10 + 8 * chunk);
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int it = tid + k * NT;
             if (it < 2 * NPOS) xt[it] = make_float4(xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA has landed
+        if (chunk < 4) TS6(11 + 8 * chunk);
+        if (!W2 || chunk == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the weight DMA has landed (W2: waited for below)
+        if (chunk < 4) TS6(12 + 8 * chunk);
         __syncthreads();
+        if (chunk < 4) TS6(13 + 8 * chunk);
+        const int cn = chunk + 1 < nchunks ? chunk + 1 : chunk;   // (uniform) the chunk whose requests ride on this one's iterations; the last asks for itself
+        bf16x8* const wcur = wsb + (W2 ? (chunk & 1) * 3 * WBLK : 0);
+        if (W2 && !(RVSR_ABL6 & 32)) request_weights(cn, wsb + ((chunk + 1) & 1) * 3 * WBLK);   // (the other buffer: read by chunk - 1, whose iterations are behind the barrier)
 
         // fixed-point scale of this chunk (dcn5_kernels.hip header): |contribution| * S <= 0.995 * 2^31 / 2304
         float S, invS;
@@ -296,23 +388,42 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
             invS = bound > 0.f ? bound * (1.f / 927407.f) : 0.f;
         }
         const bool first_of_group = c0 % d.cpg == 0;   // (uniform) later chunks of a deformable group (cpg > 8) add to its planes
-#pragma unroll
-        for (int mt = 0; mt < 3; ++mt) {
-            f32x16 acc = zero16();
-            const bf16x8* wb_hi = wsb + mt * WBLK;
+        // col_grad of M tile mt (two lane iterations' worth): issued one M tile AHEAD of its iterations (round 6), so that the matrix pipe works
+        // under the previous tile's scatter instead of in front of its own (12 MFMAs + their fragment reads stood 1.2-1.6 K cycles per tile)
+        auto col_grad_tile = [&](int mt) {
+            f32x16 a = zero16();
+            const bf16x8* wb_hi = wcur + mt * WBLK;
             const bf16x8* wb_lo = wb_hi + (2 * NK) * 32;
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 const bf16x8 ah = wb_hi[(2 * ks + hi) * 32 + lo];
-                if (RVSR_ABL6 & 8) { acc[ks] += (float)ah[0] * (float)gh[ks][0] + (float)gl[ks][1]; acc[ks + 8] += (float)ah[1]; continue; }
-                acc = ks == 0 ? mfma_bf16_first(ah, gh[0]) : mfma_bf16(ah, gh[ks], acc);
-                if (TERMS >= 2) acc = mfma_bf16(ah, gl[ks], acc);
-                if (TERMS >= 3) acc = mfma_bf16(wb_lo[(2 * ks + hi) * 32 + lo], gh[ks], acc);
+                if (RVSR_ABL6 & 8) { a[ks] += (float)ah[0] * (float)gh[ks][0] + (float)gl[ks][1]; a[ks + 8] += (float)ah[1]; continue; }
+                a = ks == 0 ? mfma_bf16_first(ah, gh[0]) : mfma_bf16(ah, gh[ks], a);
+                if (TERMS >= 2) a = mfma_bf16(ah, gl[ks], a);
+                if (TERMS >= 3) a = mfma_bf16(wb_lo[(2 * ks + hi) * 32 + lo], gh[ks], a);
             }
+            return a;
+        };
+        constexpr bool AHEAD = NK <= 4;   // (NK = 8 holds 64 registers of gOut fragments: a second accumulator tile would spill)
+        f32x16 acc_next = zero16();
+        if (AHEAD) acc_next = col_grad_tile(0);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            f32x16 acc;
+            if (AHEAD) {
+                acc = acc_next;
+                if (mt < 2) acc_next = col_grad_tile(mt + 1);
+            } else {
+                acc = col_grad_tile(mt);
+            }
+            if (chunk == 1) TS6(90 + mt);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int it = 2 * mt + s;
                 if (it >= 5) continue;   // (compile time)
+                if (chunk == 1) TS6(50 + 4 * it);
+                int fv[FRB];
+                if (G2 && chunk > 0) flush_read(gwin_prev, it * FRB, fv);   // (uniform) the previous chunk's window: this iteration's share of rows
                 const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
                 const bool has_tap = it < 4 || hi == 0;
                 const int tap = hi ? t1 : t0;
@@ -320,6 +431,11 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
                 // lanes without a pixel / a tap: zero offset, zero mask (their col_grad is 0 or belongs to zero weight rows)
                 const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
                 float m = o_m[it];
+                if (!(RVSR_ABL6 & 32)) {
+                    request_offsets(it, cn);   // (the registers just read: the next chunk's triple of this iteration)
+#pragma unroll
+                    for (int k = it; k < NXI; k += 5) request_x_item(k, cn);   // (xv is free: committed to LDS at the top of this chunk)
+                }
                 if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
                 const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
                 // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616, 722-737)
@@ -377,6 +493,7 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
                 }
                 float gm_s = gm2.x + gm2.y, gy_s = gy2.x + gy2.y, gx_s = gx2.x + gx2.y;
                 gm_s = in_tile ? gm_s : 0.f;
+                if (chunk == 1) TS6(51 + 4 * it);
                 if (far) {   // ---- rare: the whole (pixel, tap) from global memory with the reference's rule set, plain arithmetic
                     const bool vy0 = yi >= 0, vy1 = yi + 1 <= d.H - 1, vx0 = xi >= 0, vx1 = xi + 1 <= d.W - 1;
                     const int cy0 = vy0 ? yi : 0, cy1 = vy1 ? yi + 1 : d.H - 1, cx0 = vx0 ? xi : 0, cx1 = vx1 ? xi + 1 : d.W - 1;
@@ -427,35 +544,22 @@ __global__ __launch_bounds__(512, WPS) void dcn_bwdin6_kernel(const DcnBwdIn6Par
                         buf_store(gmsk_rs, sm, gk, buf_load(gmsk_rs, sm, gk) + gm_s);
                     }
                 }
+                if (G2 && chunk > 0) flush_commit(gwin_prev, c0 - 8, invS_prev, it * FRB, fv);
             }
         }
+        if (chunk < 4) TS6(14 + 8 * chunk);
         __syncthreads();
-        if (chunk + 1 < nchunks && !(RVSR_ABL6 & 32)) request(chunk + 1);   // (uniform) in flight while the window is flushed
-        // ---- flush: wave w owns channel c0 + w; one global atomic per touched cell inside the image (the halos of
-        // neighbouring workgroups overlap), cell back to zero for the next chunk
-        {
-            const unsigned cpl = (unsigned)(c0 + wave) * HW4;
-            int* gc = gwin + wave * NPOS;
-            const bool ch_ok = c0 + wave < d.C;
-            for (int base = lane; base < ((RVSR_ABL6 & 2) ? 0 : NPOS); base += 256) {   // four cells per round trip
-                int v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = base + 64 * j < NPOS ? gc[base + 64 * j] : 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (v[j] != 0) {
-                        const int pos = base + 64 * j;
-                        gc[pos] = 0;
-                        const int r = pos / TC, s = pos - r * TC;
-                        const int yy = ty0 + r, xx = tx0 + s;
-                        if (ch_ok && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W)
-                            buf_atomic_add(gx_rs, 4u * (unsigned)(yy * d.W + xx), cpl, (float)v[j] * invS);
-                    }
-                }
-            }
-        }
+        if (chunk < 4) TS6(15 + 8 * chunk);
+        if (!W2 && !(RVSR_ABL6 & 32)) request_weights(cn, wsb);   // (one weight buffer: free now; in flight while the window is flushed, waited for at the top)
+        if (W2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA issued at the top of the iterations (hipcc does not count it); the loads behind it are a barrier old
+        if (chunk < 4) TS6(16 + 8 * chunk);
+        if (!G2) flush_rows(gwin, c0, invS, 0, TR);   // (G2: during the next chunk's iterations / after the loop)
+        invS_prev = invS;
         // (the barrier after the next commit orders this flush before the next chunk's atomics)
+        if (chunk < 4) TS6(17 + 8 * chunk);
     }
+    if (G2) flush_rows(gwin0 + ((nchunks - 1) & 1) * 8 * NPOS, (nchunks - 1) * 8, invS_prev, 0, TR);   // (behind the last chunk's barrier)
+    TS6(9);
 }
 
 // (dcn5_kernels.hip)
@@ -470,13 +574,22 @@ size_t rvsr_dcn_bwdin6_workspace_bytes(int Co, int C) {
 template <int NK, int R>
 static int launch_bwdin6(const DcnBwdIn6Params& p, const bf16x8* wpack, hipStream_t st) {
     constexpr int TH = 8, TR = TH + 2 * R + 3, TC = 32 + 2 * R + 3, NPOS = TR * TC;
-    constexpr size_t lds = (size_t)NPOS * (2 * 16 + 8 * 4) + (size_t)3 * 2 * (2 * NK) * 32 * 16 + 8 * sizeof(float);
-    constexpr int WPS = lds <= 80 * 1024 && NK <= 4 ? 2 : 1;   // (two workgroups per CU where LDS allows: the register budget follows)
-    auto k = dcn_bwdin6_kernel<NK, R, 3, WPS>;
+    constexpr size_t wbytes = (size_t)3 * 2 * (2 * NK) * 32 * 16;
+    constexpr size_t lds1 = (size_t)NPOS * (2 * 16 + 8 * 4) + wbytes + 8 * sizeof(float);
+    // 160 KB of LDS for ONE workgroup per CU: a second grad_input window first (the flush moves into the next chunk's iterations), then a
+    // second weight buffer (the DMA moves to the top of the iterations) where they fit
+    constexpr size_t gbytes = (size_t)NPOS * 8 * 4;
+    // (NK = 8, the nf128 packs: the 48 KB weight block first -- measured at R = 5, where only one of the two fits: 4.01 against 4.21 ms)
+    constexpr bool W2_FIRST = NK >= 8;
+    constexpr bool G2 = RVSR_BWDIN6_G2 && lds1 + gbytes + (W2_FIRST && lds1 + wbytes <= 160 * 1024 ? wbytes : 0) <= 160 * 1024;
+    constexpr bool W2 = lds1 + (G2 ? gbytes : 0) + wbytes <= 160 * 1024;
+    constexpr size_t lds = lds1 + (G2 ? gbytes : 0) + (W2 ? wbytes : 0);
+    constexpr int WPS = 2;   // waves per SIMD the launch bounds name: ONE 8-wave workgroup per CU (~220 registers per lane)
+    auto k = dcn_bwdin6_kernel<NK, R, 3, WPS, W2, G2>;
     if constexpr (NK >= 4) {   // reduced-term products (gemm modes 2 / 3): the kernels of the nf64 / nf128 packs
         const int nt = rvsr_gemm_terms();
-        if (nt == 2) k = dcn_bwdin6_kernel<NK, R, 2, WPS>;
-        if (nt == 1) k = dcn_bwdin6_kernel<NK, R, 1, WPS>;
+        if (nt == 2) k = dcn_bwdin6_kernel<NK, R, 2, WPS, W2, G2>;
+        if (nt == 1) k = dcn_bwdin6_kernel<NK, R, 1, WPS, W2, G2>;
     }
     if (set_lds(k, lds)) FAIL(RVSR_ERR_LAUNCH, "dcn_bwdin6: cannot reserve %zu B of LDS", lds);
     const DcnGeom& d = p.d;
@@ -676,35 +789,35 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         const int oy = y0 + wave, ox = x0 + lo;
         return 4u * (unsigned)((oy < d.Ho && ox < d.Wo) ? oy * d.Wo + ox : y0 * d.Wo + x0);
     };
-    auto request_x = [&](int b, int y0, int x0) {
+    // x-tile item k of this thread for the tile at (b, y0, x0): item = (quad, row, col), recomputed per tile (division by a constant: a handful of
+    // instructions); a position outside the image (or no item) gets a lane offset beyond the 2 GB view, for which the buffer load returns 0
+    auto request_x_item = [&](int k, int b, int y0, int x0) {
         const __amdgpu_buffer_rsrc_t x_rs = buf_view_2g(d.x + (size_t)b * d.C * HW);
         const int ty0 = y0 - d.pad - R, tx0 = x0 - d.pad - R;
+        const int it = tid + k * NT;
+        const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
+        const int rr_ = pos / TC;
+        const int gy = ty0 + rr_, gx = tx0 + (pos - rr_ * TC);
+        const bool ok = it < 2 * NPOS && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+        const unsigned xo = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * quad) * HW) : 0x80000000u;
 #pragma unroll
-        for (int k = 0; k < NXI; ++k) {   // item = (quad, row, col), recomputed per tile (division by a constant: a handful of instructions)
-            const int it = tid + k * NT;
-            const int quad = it >= NPOS ? 1 : 0, pos = it - quad * NPOS;
-            const int rr_ = pos / TC;
-            const int gy = ty0 + rr_, gx = tx0 + (pos - rr_ * TC);
-            const bool ok = it < 2 * NPOS && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
-            const unsigned xo = ok ? 4u * ((unsigned)(gy * d.W + gx) + (unsigned)(4 * quad) * HW) : 0x80000000u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xo, (unsigned)(c0 + e) * HW4);
-        }
+        for (int e = 0; e < 4; ++e) xv[k][e] = buf_load(x_rs, xo, (unsigned)(c0 + e) * HW4);
     };
-    // the wave's 8 operand vectors of a tile by LDS-DMA (16 B per lane, no registers): lane l of the wave lands at its slot + 16 l
-    auto fetch_ag = [&](int b, int y0, int x0, int set) {
+    // operand vectors v0 .. v1 - 1 (of 8) of the wave for a tile by LDS-DMA (16 B per lane, no registers): lane l of the wave lands at its slot + 16 l
+    auto fetch_ag = [&](int b, int y0, int x0, int set, int v0, int v1) {
         const bf16x8* src = p.agt + ((((size_t)b * p.agt_rows + (y0 + wave)) * d.ntx + (x0 >> 5)) * p.agt_nmb32 + 2 * mbw) * (size_t)(4 * 64) + lane;
         bf16x8* dst = agt + ((set * TH + wave) * 8) * 64 + lane;
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
+        for (int v = v0; v < v1; ++v)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + v * 64),
                                              (__attribute__((address_space(3))) void*)(dst + v * 64), 16, 0, 0);
     };
     if (t_begin < t_end) {
         int b, y0, x0;
         tile_coords(t_begin, b, y0, x0);
-        fetch_ag(b, y0, x0, 0);
-        request_x(b, y0, x0);
+        fetch_ag(b, y0, x0, 0, 0, 8);
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) request_x_item(k, b, y0, x0);
         const __amdgpu_buffer_rsrc_t off_rs = buf_view(d.offset + (size_t)b * d.off_bs), msk_rs = buf_view(d.mask + (size_t)b * d.mask_bs);
         const unsigned pv = pixel_offset(y0, x0);
 #pragma unroll
@@ -720,31 +833,41 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
         const float by = (float)(oy - d.pad), bx = (float)(ox - d.pad);
         const int set = (t - t_begin) & 1;
         bf16x8* my_ag = agt + ((set * TH + wave) * 8) * 64 + lane;   // vector (mb, ks, part) at [(mb * 4 + ks * 2 + part) * 64]
+        const bool tl = t == t_begin + 2;
+        if (tl) TW6(0);
         // ---- this tile's operand vectors have landed (requested a tile ago; hipcc does not count LDS-DMA); commit the x tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tl) TW6(1);
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int it = tid + k * NT;
             if (it < 2 * NPOS) xt[it] = make_float4(xv[k][0], xv[k][1], xv[k][2], xv[k][3]);
         }
         __syncthreads();
-        // ---- the next tile's requests (the last tile asks for itself again: unconditional loads keep hipcc's s_waitcnt bookkeeping simple)
+        if (tl) TW6(2);
+        // ---- the next tile's requests (the last tile asks for itself again: unconditional loads keep hipcc's s_waitcnt bookkeeping simple).
+        // They are issued a slice per lane iteration below, not as one burst here: 39 vector-memory instructions per wave in a row took 3.6 K of a
+        // tile's 14 K cycles to ISSUE (the texture path takes ~100 cycles per instruction with eight waves asking at once) and the first iteration
+        // then waited another 1.5 K behind them (profiles/r06_notes.md: timeline)
         int bn, y0n, x0n;
         tile_coords(t + 1 < t_end ? t + 1 : t, bn, y0n, x0n);
-        fetch_ag(bn, y0n, x0n, set ^ 1);
-        request_x(bn, y0n, x0n);
         const __amdgpu_buffer_rsrc_t off_rs_n = buf_view(d.offset + (size_t)bn * d.off_bs), msk_rs_n = buf_view(d.mask + (size_t)bn * d.mask_bs);
         const unsigned pv_n = pixel_offset(y0n, x0n);
 
+        if (tl) TW6(3);
         f32x16 dt_h, dt_l;   // column values of two lane iterations, transposed: D[i = pixel][j = 16 (it & 1) + 8 h + ch]
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
             const bool has_tap = it < 4 || hi == 0;
             const bool act_lane = px_ok && has_tap;
+            if (tl) TW6(10 + 4 * it);
             const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
             float m = o_m[it];
             request_offsets(it, off_rs_n, msk_rs_n, pv_n);   // (the registers just read: the next tile's triple of this iteration)
+            if (it < 4) fetch_ag(bn, y0n, x0n, set ^ 1, 2 * it, 2 * it + 2);
+#pragma unroll
+            for (int k = it; k < NXI; k += 5) request_x_item(k, bn, y0n, x0n);   // (xv is free: committed to LDS above)
             if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
             const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
             // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616)
@@ -798,6 +921,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
 #pragma unroll
                 for (int e = 0; e < 8; ++e) colv[e] = u00 * q00[e] + u01 * q01[e] + u10 * q10[e] + u11 * q11[e];
             }
+            if (tl) TW6(11 + 4 * it);
             // (spare slot of iteration 4, half 1: the ones column of the bias gradient)
             if (it == 4) colv[0] = hi ? (px_ok ? 1.f : 0.f) : colv[0];
             bf16x8 ch_, cl_;
@@ -809,6 +933,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
                 dt_h = mfma_bf16(ch_, sel_o, dt_h);
                 if (TERMS >= 2) dt_l = mfma_bf16(cl_, sel_o, dt_l);
             }
+            if (tl) TW6(12 + 4 * it);
             if ((it & 1) || it == 4) {   // ---- n-block nb = it / 2 complete: gw_acc[mb][nb] += gOut^T[mb] x col, K = this row's 32 pixels
                 const int nb = it >> 1;
 #pragma unroll
@@ -826,7 +951,9 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
                 }
             }
         }
+        if (tl) TW6(4);
         __syncthreads();   // (every wave is done with the x tile)
+        if (tl) TW6(5);
     }
 
     // ---- partial of this (stream, unit): sum of the waves (rows), fixed order, through LDS.  The last tile asked for itself again: that

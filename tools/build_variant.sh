@@ -1,13 +1,14 @@
 #!/bin/bash
-# Scratch build of ONE kernel file with extra -D flags into realvsr_amd/csrc/librealvsr_<name>.so (load with RVSR_SO=...):
-#   tools/build_variant.sh dcn4_kernels abl1 -DRVSR_ABL4=1
+# Variant build of ONE source file of the library (the other objects are the product's): tools/build_variant.sh <name> <file.hip> [flags / sed script]
+#   tools/build_variant.sh lb4 dcn6_kernels.hip -DRVSR_X=1            ->  realvsr_amd/csrc/librealvsr_lb4.so
+#   SED='s/a/b/' tools/build_variant.sh v2 dcn6_kernels.hip           (the sed script is applied to a copy of the file first)
 set -e
-STEM="$1"; NAME="$2"; shift; shift
-T=$(mktemp -d)
-cp realvsr_amd/csrc/*.hip realvsr_amd/csrc/*.h realvsr_amd/csrc/*.inc realvsr_amd/csrc/Makefile "$T"/
-cp realvsr_amd/csrc/*.o "$T"/ 2>/dev/null || true
-rm -f "$T"/$STEM.o "$T"/librealvsr_hip.so
-make -s -C "$T" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function $*" > /dev/null
-cp "$T/librealvsr_hip.so" realvsr_amd/csrc/librealvsr_$NAME.so
-rm -rf "$T"
+NAME=$1; SRC=$2; shift 2
+cd "$(dirname "$0")/../realvsr_amd/csrc"
+F=$SRC
+if [ -n "$SED" ]; then F=_variant_$NAME.hip; sed "$SED" $SRC > $F; fi
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function "$@" -c $F -o /tmp/variant_$NAME.o
+[ "$F" != "$SRC" ] && rm -f $F
+OBJS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/variant_$NAME.o -o librealvsr_$NAME.so
 echo built librealvsr_$NAME.so
