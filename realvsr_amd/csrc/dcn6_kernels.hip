@@ -404,7 +404,12 @@ __global__ __launch_bounds__(512, WPS * RVSR_BWDIN6_LBMUL) void dcn_bwdin6_kerne
             }
             return a;
         };
-        constexpr bool AHEAD = NK <= 4;   // (NK = 8 holds 64 registers of gOut fragments: a second accumulator tile would spill)
+        // AHEAD: M tile 0 at the top of the chunk; the MFMAs of tile mt + 1 INSIDE the two lane iterations of tile mt, a k-step behind each of their
+        // first channel pairs, with the weight fragments read at the top of the iteration (in front of its atomics).  As a block between the
+        // iterations a tile's 12 MFMAs stood 1.4-2.3 K cycles (fragment reads queued behind 32 LDS atomics, then both waves of the SIMD on the
+        // matrix pipe): a quarter of a chunk (timeline in profiles/r06_notes.md).
+        constexpr bool AHEAD = NK <= 4 && R <= 5;   // (NK = 8 holds 64 registers of gOut fragments, R >= 8 24 of x-tile items: a second accumulator tile would spill)
+        constexpr int KH = (NK + 1) / 2;  // k-steps of the next tile per lane iteration
         f32x16 acc_next = zero16();
         if (AHEAD) acc_next = col_grad_tile(0);
 #pragma unroll
@@ -412,7 +417,6 @@ __global__ __launch_bounds__(512, WPS * RVSR_BWDIN6_LBMUL) void dcn_bwdin6_kerne
             f32x16 acc;
             if (AHEAD) {
                 acc = acc_next;
-                if (mt < 2) acc_next = col_grad_tile(mt + 1);
             } else {
                 acc = col_grad_tile(mt);
             }
@@ -424,6 +428,21 @@ __global__ __launch_bounds__(512, WPS * RVSR_BWDIN6_LBMUL) void dcn_bwdin6_kerne
                 if (chunk == 1) TS6(50 + 4 * it);
                 int fv[FRB];
                 if (G2 && chunk > 0) flush_read(gwin_prev, it * FRB, fv);   // (uniform) the previous chunk's window: this iteration's share of rows
+                // weight fragments of this iteration's share of the NEXT M tile (k-steps ks0 .. ks0 + KH - 1)
+                const bool pre = AHEAD && mt < 2;      // (constant after unrolling)
+                const int ks0 = s * KH;
+                bf16x8 fh[KH], fl[KH];
+                if (pre) {
+                    const bf16x8* nb_hi = wcur + (mt + 1) * WBLK;
+                    const bf16x8* nb_lo = nb_hi + (2 * NK) * 32;
+#pragma unroll
+                    for (int j = 0; j < KH; ++j) {
+                        if (ks0 + j < NK) {
+                            fh[j] = nb_hi[(2 * (ks0 + j) + hi) * 32 + lo];
+                            if (TERMS >= 3) fl[j] = nb_lo[(2 * (ks0 + j) + hi) * 32 + lo];
+                        }
+                    }
+                }
                 const int t0 = bwd6_tap(it, 0), t1 = it < 4 ? bwd6_tap(it, 1) : 0;
                 const bool has_tap = it < 4 || hi == 0;
                 const int tap = hi ? t1 : t0;
@@ -453,10 +472,15 @@ __global__ __launch_bounds__(512, WPS * RVSR_BWDIN6_LBMUL) void dcn_bwdin6_kerne
                 const f32x2 W01 = {hy * hx, hy * lx}, W23 = {ly * hx, ly * lx};
                 f32x2 gm2 = {0.f, 0.f}, gy2 = {0.f, 0.f}, gx2 = {0.f, 0.f};
                 int* wq = gwin + pos0;
+                float4 cr[2][4];   // both quads' corners up front: read inside the loop, the second quad's waited for the first quad's 16 atomics
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const float4* xq = xt + q * NPOS + ((RVSR_ABL6 & 4) ? 0 : pos0);
-                    float4 a00 = xq[0], a01 = xq[1], a10 = xq[TC], a11 = xq[TC + 1];
+                    cr[q][0] = xq[0]; cr[q][1] = xq[1]; cr[q][2] = xq[TC]; cr[q][3] = xq[TC + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float4 a00 = cr[q][0], a01 = cr[q][1], a10 = cr[q][2], a11 = cr[q][3];
                     if (RVSR_ABL6 & 4) { a00 = make_float4(ly, lx, hy, hx); a01 = make_float4(lx, ly, hx, hy); a10 = a01; a11 = a00; }
 #pragma unroll
                     for (int ph = 0; ph < 2; ++ph) {       // channel pairs (2 pr, 2 pr + 1), pr = 2 q + ph
@@ -489,6 +513,12 @@ __global__ __launch_bounds__(512, WPS * RVSR_BWDIN6_LBMUL) void dcn_bwdin6_kerne
                         lds_add_i32_6(q1 + 1, (int)(__float_as_uint(u01.y) - 0x4B400000u));
                         lds_add_i32_6(q1 + TC, (int)(__float_as_uint(u10.y) - 0x4B400000u));
                         lds_add_i32_6(q1 + TC + 1, (int)(__float_as_uint(u11.y) - 0x4B400000u));
+                        if (pre && pr < KH && ks0 + pr < NK && !(RVSR_ABL6 & 8)) {   // (compile time) one k-step of the next M tile
+                            const int ks = ks0 + (pr < KH ? pr : 0);
+                            acc_next = ks == 0 ? mfma_bf16_first(fh[pr < KH ? pr : 0], gh[0]) : mfma_bf16(fh[pr < KH ? pr : 0], gh[ks < NK ? ks : 0], acc_next);
+                            if (TERMS >= 2) acc_next = mfma_bf16(fh[pr < KH ? pr : 0], gl[ks < NK ? ks : 0], acc_next);
+                            if (TERMS >= 3) acc_next = mfma_bf16(fl[pr < KH ? pr : 0], gh[ks < NK ? ks : 0], acc_next);
+                        }
                     }
                 }
                 float gm_s = gm2.x + gm2.y, gy_s = gy2.x + gy2.y, gx_s = gx2.x + gx2.y;
