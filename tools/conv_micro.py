@@ -46,5 +46,7 @@ if os.environ.get('RVSR_MICRO_CHECK'):
             ref = F.leaky_relu(ref, 0.1)
         err = (y[:2].double() - ref).pow(2).sum().sqrt() / ref.pow(2).sum().sqrt()
     print('  l2 error of the output against an f64 conv: %.2e' % err.item())
+if os.environ.get('RVSR_MICRO_HASH'):
+    print('  output hash %d' % int(y.detach().view(torch.int32).to(torch.int64).sum().item()))
 print('conv %s: %.3f ms/iter, %.1f TFLOP/s (f32-equivalent), %.3f ns/px' % ('fwd+bwd' if a.bwd else 'fwd', ms, flop / ms / 1e9,
                                                                               ms * 1e6 / (a.B * a.H * a.W)))
