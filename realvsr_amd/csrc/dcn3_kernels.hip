@@ -229,6 +229,7 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
         const float4* xq0 = xt + (2 * hi) * NPOS;  // channels cb8..cb8+3 (xq0[NPOS + pos]: cb8+4..cb8+7)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            if (chunk == 1) TSTAMP(60 + 5 * tap);
             const float dy = n_dy, dx = n_dx;
             float m = n_m;
             if (ABL3 & 32) { n_dy = (float)lane * 1e-3f; n_dx = n_dy; n_m = 0.5f; }
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
                 a00 = xq0[pos]; b00 = xq0[NPOS + pos]; a01 = xq0[pos + 1]; b01 = xq0[NPOS + pos + 1];
                 a10 = xq0[pos + TC]; b10 = xq0[NPOS + pos + TC]; a11 = xq0[pos + TC + 1]; b11 = xq0[NPOS + pos + TC + 1];
             }
+            if (chunk == 1) TSTAMP(61 + 5 * tap);
             const f32x2 p0 = blend4(wsd, wt, lo2(a00), lo2(a01), lo2(a10), lo2(a11));
             const f32x2 p1 = blend4(wsd, wt, hi2(a00), hi2(a01), hi2(a10), hi2(a11));
             const f32x2 p2 = blend4(wsd, wt, lo2(b00), lo2(b01), lo2(b10), lo2(b11));
@@ -292,10 +294,12 @@ __global__ __launch_bounds__(512, (MT <= 2 && R == 3) ? 4 : 2) void dcn_fwd3_ker
                         v[j] = cb8 + j < d.C ? u00 * q00[j] + u01 * q01[j] + u10 * q10[j] + u11 * q11[j] : 0.f;
                 }
             }
+            if (chunk == 1) TSTAMP(62 + 5 * tap);
             bf16x8 bh, bl;
             if (ABL3 & 16) { bh = __builtin_bit_cast(bf16x8, make_float4(v[0], v[1], v[2], v[3])); bl = __builtin_bit_cast(bf16x8, make_float4(v[4], v[5], v[6], v[7])); }
             else split8(v, bh, bl);
             if (ABL3 & 1) { acc[0][0] += (float)bh[0] + (float)bl[1]; continue; }
+            if (chunk == 1) TSTAMP(63 + 5 * tap);
             bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {

@@ -29,3 +29,7 @@ for i in sorted(names):
     print('%-30s +%7d  (t=%d)' % (names[i], t[i] - prev, t[i] - t[0]))
     prev = t[i]
 print('chunk1 taps:', [t[40 + k] - (t[4 + 6] if k == 0 else t[39 + k]) for k in range(9)])
+print('chunk1, inside each tap (cycles): offsets consumed + geometry + corner reads issued | corner reads back | blend (+ far path) | split | fragment reads + MFMAs issued')
+for k in range(9):
+    a = [t[60 + 5 * k + j] for j in range(4)] + [t[40 + k]]
+    print('  tap %d: %s' % (k, ' | '.join('%5d' % (a[j + 1] - a[j]) for j in range(4))), ' (tap start at t=%d)' % (a[0] - t[0]))
