@@ -94,10 +94,15 @@ int rvsr_modulated_deform_conv_forward(const float* input, const float* weight, 
  *   caller zeroes them (deform_conv.py:130-131, cpp:659-671).
  *   grad_input/grad_offset/grad_mask may be NULL together (skip), grad_weight may be NULL (skip).
  *   workspace: rvsr_modulated_deform_conv_backward_workspace_bytes() bytes, needed iff grad_weight.
- *   The kernel for grad_input/grad_offset/grad_mask is chosen ON THE DEVICE from a sampled statistic
- *   of `offset` (no host synchronisation): atomic-free private LDS windows for offsets within ~2 px,
- *   a shared LDS tile with a 3 px / 5 px halo for larger ones; all candidates give the same result up
- *   to the summation order of the scatter. */
+ *   SIZE: for stride 1 / dilation 1 / channels % 8 == 0 / channels_out <= 128 (what EDVR and TDAN instantiate) the workspace also holds the
+ *   hand-off between the input-gradient and the weight-gradient kernel -- a bf16 hi + lo copy of grad_output in matrix-core operand order,
+ *   batch x ceil8(Ho) x ceil32(Wo) x ceil64(channels_out) x 4 bytes (~575 MiB at 40 x 64 x 180 x 320) -- on top of the weight image and the
+ *   weight-gradient partials (tens of MB).  Other geometries: partials only.
+ *   The kernel for grad_input/grad_offset/grad_mask is chosen ON THE DEVICE from a sampled statistic of `offset` (no host
+ *   synchronisation): one shared fixed-point LDS window per 8-channel chunk with a halo of 2 / 4 / 5 / 8 / 12 px; samples beyond the halo
+ *   go through global gathers / atomics with the reference's rule set; all candidates give the same result up to the summation order of
+ *   the scatter.  grad_weight / grad_bias / grad_offset / grad_mask are bit-reproducible run to run, grad_input is not (atomics, as the
+ *   reference's col2im, kernel.cu:688). */
 size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch, int channels, int height, int width,
                                                            int channels_out, int stride, int pad, int dil);
 int rvsr_modulated_deform_conv_backward(const float* input, const float* weight, const float* bias,

@@ -131,7 +131,12 @@ def set_gemm_mode(mode):
              than 32 output channels form a product as a1*b1 in f16 + (a1*b2 + a2*b1) in fp8 e4m3 (a1 = f16(a), a2 = a - a1): 56 instead of
              108 matrix instructions per 16-channel stage, ~1.2e-5 instead of 4.6e-6 per convolution.  It is a per-call
              flag of rvsr_conv2d_forward (w_mode | 4) that realvsr_amd.functional sets while this mode is selected; data and weight
-             gradients, the DCN kernels and every other conv keep the three-term bf16 split."""
+             gradients, the DCN kernels and every other conv keep the three-term bf16 split.
+             VALID RANGE (the fp8 pieces are stored unscaled; csrc/bf16x3.h): the cross terms carry their ~4 bits only while |w| and |x| stay
+             within e4m3's normal range after the 2^12 residual scale -- |x| <~ 200 (beyond it the residual piece saturates at 448) and
+             |w| >~ 2^-6 for the a1 piece (smaller weights -- EDVR's 0.1-scaled kaiming residual blocks, std ~0.006 -- quantise towards 0
+             and the format degrades to its f16 main term, ~5e-4 per product, on those layers); |v| > 65504 overflows f16.  Measured on the
+             bench network (default + rescaled init): output 2.5e-7 of the oracle's; it is an opt-in speed mode, not the reference arithmetic."""
     global _fmt_f16fp8
     lib().rvsr_set_gemm_mode(GEMM_MODES[mode])
     _fmt_f16fp8 = mode == 'f16fp8'
@@ -144,6 +149,10 @@ def fmt_f16fp8():
 def set_gemm_mode_thread(mode):
     """The same choice for the calling host thread only (None: back to the process-wide setting).  Race-free per-call selection when
     several host threads drive the library (nn.DataParallel replicas): every entry point reads the mode on the calling thread."""
+    if mode == 'f16fp8':
+        # the f16 + fp8 format is a process-wide Python flag on top of library mode 0 (set_gemm_mode): selecting it per thread would silently
+        # run the three-term split instead
+        raise ValueError("set_gemm_mode_thread: 'f16fp8' is a process-wide format (set_gemm_mode('f16fp8')), not a per-thread mode")
     lib().rvsr_set_gemm_mode_thread(-1 if mode is None else GEMM_MODES[mode])
 
 

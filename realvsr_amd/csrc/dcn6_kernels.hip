@@ -633,7 +633,7 @@ static int launch_bwdin6(const DcnBwdIn6Params& p, const bf16x8* wpack, hipStrea
 template <int NK>
 static int launch_bwdin6_halo(const DcnBwdIn6Params& p, const bf16x8* wpack, int halo, hipStream_t st) {
     if (halo <= 2) return launch_bwdin6<NK, 2>(p, wpack, st);
-    if constexpr (NK <= 4) if (halo <= 4) return launch_bwdin6<NK, 4>(p, wpack, st);   // (77 KB: the largest window that still fits twice per CU)
+    if (halo <= 4) return launch_bwdin6<NK, 4>(p, wpack, st);
     if (halo <= 5) return launch_bwdin6<NK, 5>(p, wpack, st);
     if (halo <= 8) return launch_bwdin6<NK, 8>(p, wpack, st);
     if constexpr (NK <= 4) return launch_bwdin6<NK, 12>(p, wpack, st);   // (12 px + the 48 KB weight block of NK = 8 exceed 160 KB)
@@ -705,8 +705,8 @@ int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g
             if (rc != RVSR_OK) return rc;
         }
     } else {
-        const int halos[3] = {2, 5, 8}, ge[3] = {-1, 0, 2}, lt[3] = {0, 2, -1};
-        for (int k = 0; k < 3; ++k) {
+        const int halos[4] = {2, 4, 5, 8}, ge[4] = {-1, 0, 1, 2}, lt[4] = {0, 1, 2, -1};
+        for (int k = 0; k < 4; ++k) {
             p.sel.ge = ge[k]; p.sel.lt = lt[k];
             BWDIN6_DISPATCH(halos[k]);
             if (rc != RVSR_OK) return rc;

@@ -427,6 +427,14 @@ extern "C" size_t rvsr_modulated_deform_conv_forward_workspace_bytes(int channel
     return rvsr_dcn_fwd2_workspace_bytes(channels_out, channels);
 }
 
+// Can the dcn_bwdin6 / dcn_bwdw6 pair take a call of this geometry?  (The workspace query has no deformable_groups argument: the offset planes of
+// one batch element are bounded by their worst case, 18 planes per 8 channels; rvsr_launch_dcn_bwdin6 repeats the exact test.)  The query sizes the
+// hand-off buffer and the backward offers it to the pair by this one predicate.
+static bool dcn_bwd6_pair_possible(int channels, int height, int width, int channels_out, int stride, int dil) {
+    const size_t planes = (size_t)(channels / 8) * 18 > (size_t)channels ? (size_t)(channels / 8) * 18 : (size_t)channels;
+    return stride == 1 && dil == 1 && channels % 8 == 0 && channels_out <= 128 &&
+           planes * (size_t)height * width * sizeof(float) < ((size_t)1 << 31);
+}
 // everything but the operand buffer dcn_bwdin6 hands to dcn_bwdw6 (that buffer sits behind it, 256-byte aligned)
 static size_t dcn_backward_workspace_base(int batch, int channels, int height, int width, int channels_out, int stride, int pad, int dil) {
     const int Ho = (height + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * 2 + 1)) / stride + 1;
@@ -445,7 +453,9 @@ extern "C" size_t rvsr_modulated_deform_conv_backward_workspace_bytes(int batch,
                                                                       int channels_out, int stride, int pad, int dil) {
     const int Ho = (height + 2 * pad - (dil * 2 + 1)) / stride + 1, Wo = (width + 2 * pad - (dil * 2 + 1)) / stride + 1;
     size_t n = dcn_backward_workspace_base(batch, channels, height, width, channels_out, stride, pad, dil);
-    if (stride == 1 && dil == 1 && channels % 8 == 0 && channels_out <= 128) n += rvsr_dcn_bwd6_agt_bytes(batch, channels_out, Ho, Wo);
+    // the gOut^T hand-off of the dcn_bwdin6 / dcn_bwdw6 pair (hi + lo bf16 copy of gOut, 8-row x 32-column tiles: ~575 MiB at B = 40, Co = 64,
+    // 180 x 320): only for calls that pair can take
+    if (dcn_bwd6_pair_possible(channels, height, width, channels_out, stride, dil)) n += rvsr_dcn_bwd6_agt_bytes(batch, channels_out, Ho, Wo);
     return n;
 }
 
@@ -458,16 +468,18 @@ static int dcn_backward_impl(DcnGeom& d, const float* weight, const float* gout,
     g.p = gout; g.act = gact; g.slope = gact_slope; g.C = d.Co; g.Hs = g.Hv = d.Ho; g.Ws = g.Wv = d.Wo; g.mode = 0;
     const int nty = (d.Ho + 3) / 4;
     // dcn_bwdin6 + dcn_bwdw6 run as a pair: the first leaves gOut (x act') behind as the matrix-core operands of the second
-    static const int genw = [] { const char* e = getenv("RVSR_DCN_BWDW"); return e ? atoi(e) : 6; }();   // developer A/B switch
+    // developer A/B switch RVSR_DCN_BWD: 7 (default) = dcn_bwdin6 + dcn_bwdw6, 64 = dcn_bwdin6 + dcn_bwdw4, 6 = dcn_bwdin5 + dcn_bwdw4 (round 4's pair)
+    static const int gen_env = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();
+    static const int genw = gen_env == 7 ? 6 : 4;
     void* agt = nullptr;
     bool agt_written = false;
-    if (gx && gw && rvsr_gemm_mode_now() != 1 && genw >= 6 && d.stride == 1 && d.dil == 1 && d.C % 8 == 0 && d.Co <= 128)
+    if (gx && gw && rvsr_gemm_mode_now() != 1 && genw >= 6 && dcn_bwd6_pair_possible(d.C, d.H, d.W, d.Co, d.stride, d.dil))
         agt = (unsigned char*)workspace + dcn_backward_workspace_base(d.B, d.C, d.H, d.W, d.Co, d.stride, d.pad, d.dil);
     if (gx || goff || gmask) {
         if (!gx || !goff || !gmask) FAIL(RVSR_ERR_BAD_ARG, "dcn backward: grad_input/grad_offset/grad_mask must be given together");
         int rc2 = RVSR_ERR_UNSUPPORTED;
         if (rvsr_gemm_mode_now() != 1) {
-            static const int gen = [] { const char* e = getenv("RVSR_DCN_BWD"); return e ? atoi(e) : 7; }();  // developer A/B switch
+            static const int gen = gen_env == 64 ? 7 : gen_env;
             static const int halo = [] { const char* e = getenv("RVSR_DCN5_HALO"); return e ? atoi(e) : -1; }();   // -1: selected on the device
             if (gen >= 7) {
                 rc2 = rvsr_launch_dcn_bwdin6(d, weight, g, gx, goff, goff_bs, gmask, gmask_bs, workspace, workspace_bytes, st, halo, probe, agt);

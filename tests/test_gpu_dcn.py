@@ -60,10 +60,10 @@ SHAPES = [
     (1, 16, 16, 2, 11, 13, 1, 2, 2, 1.0, True),     # dilation 2
     (1, 8, 72, 1, 6, 34, 1, 1, 1, 1.0, True),       # Co > 64 (MT=4 path), dg 1
     (1, 64, 80, 8, 10, 36, 1, 1, 1, 0.5, True),     # backward in two output-channel passes (64 + 16)
-    # the backward picks its kernel on the device from the offsets (dcn2_kernels.hip, rvsr_launch_dcn_bwdin_auto):
-    (1, 64, 64, 8, 24, 40, 1, 1, 1, 3.0, True),     # 40 % of the components beyond 2.5 px: dcn_bwdin2, 3 px halo
-    (1, 64, 64, 8, 24, 40, 1, 1, 1, 6.0, True),     # 68 %: dcn_bwdin2, 5 px halo
-    (1, 128, 128, 8, 17, 40, 1, 1, 1, 8.0, True),   # Co > 64: the 5 px halo does not fit, 3 px halo at any offset size
+    # the backward picks its window halo on the device from the offsets (dcn6_kernels.hip, rvsr_launch_dcn_bwdin6: 2 / 4 / 5 / 8 / 12 px):
+    (1, 64, 64, 8, 24, 40, 1, 1, 1, 3.0, True),     # 40 % of the components beyond 2.5 px: the 5 px window
+    (1, 64, 64, 8, 24, 40, 1, 1, 1, 6.0, True),     # 68 %: the 12 px window
+    (1, 128, 128, 8, 17, 40, 1, 1, 1, 8.0, True),   # Co > 64 (NK = 8): windows 2 / 4 / 5 / 8 px only
 ]
 
 

@@ -1,4 +1,4 @@
-"""s_memtime timeline of one dcn_fwd3_kernel workgroup (build: tools/build_timeline.sh; run with RVSR_SO=...librealvsr_tl.so)."""
+"""s_memtime timeline of one dcn_fwd3_kernel workgroup (build: tools/build_variant.sh tl3 dcn3_kernels.hip -DRVSR_TIMELINE_DCN; run with RVSR_SO=$PWD/realvsr_amd/csrc/librealvsr_tl3.so)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from realvsr_amd import functional as RF

@@ -1,5 +1,5 @@
 """s_memtime timeline of one wave (wave 3 of workgroup 77, batch element 1) of dcn_bwdin5_kernel at the L1 shape.
-   tools/build_variant5.sh tl -DRVSR_TIMELINE_DCN5 ; RVSR_SO=$PWD/realvsr_amd/csrc/librealvsr_tl.so python tools/dcn5_timeline.py [ostd]"""
+   tools/build_variant.sh tl5 dcn5_kernels.hip -DRVSR_TIMELINE_DCN5 ; RVSR_SO=$PWD/realvsr_amd/csrc/librealvsr_tl5.so python tools/dcn5_timeline.py [ostd]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from realvsr_amd import functional as RF

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 6: DCN backward restructure, one call: parity of the DCN suites, per-kernel A/B of library variants, timeline
-#   tools/r06_bwd_step.sh [variant specs for tools/ab_kernels.sh ...]
+# DCN backward, one gpurun call: parity of the DCN suites, per-kernel A/B of library variants, timeline
+#   tools/dcn_bwd_ab.sh [variant specs for tools/ab_kernels.sh ...]
 mkdir -p gpurun_out
-L=gpurun_out/r06_bwd_step.log
+L=gpurun_out/dcn_bwd_ab.log
 : > $L
 timeout 1500 python -m pytest tests/test_gpu_dcn.py tests/test_gpu_dcn_fullsize.py -x -q -m gpu 2>&1 | tail -6 >> $L
 bash tools/ab_kernels.sh "$@" >> $L 2>&1

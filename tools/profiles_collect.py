@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Copy the artefacts of tools/r05_profiles.sh (gpurun_out/r05_profiles/) into profiles/ under r05_ names and derive
-  r05_dcn_fwd_pmc.json / r05_dcn_fwd_pmc_nf128.json  the DCN-forward HBM-traffic records bench.py rescales (FETCH_SIZE x2 + WRITE_SIZE,
+"""Copy the artefacts of tools/profiles.sh (gpurun_out/<round>_profiles/) into profiles/ under <round>_ names and derive
+  <round>_dcn_fwd_pmc.json / <round>_dcn_fwd_pmc_nf128.json  the DCN-forward HBM-traffic records bench.py rescales (FETCH_SIZE x2 + WRITE_SIZE,
                                                       MI355X_MICROARCH.md HBM section), offset std 1.25 px;
-  r05_dcn_sq_counters.json                            SQ counters of dcn_fwd3 at nf64 / nf128;
-  r05_dcn_bwd_sq_counters.json                        SQ counters + HBM traffic of the backward pair dcn_bwdin6 / dcn_bwdw6.
+  <round>_dcn_sq_counters.json                            SQ counters of dcn_fwd3 at nf64 / nf128;
+  <round>_dcn_bwd_sq_counters.json                        SQ counters + HBM traffic of the backward pair dcn_bwdin6 / dcn_bwdw6.
 A kernel family launches several template instantiations per call (halo candidates that return at once unless selected): the record keeps,
 per counter, the instantiation that did the work (the largest mean)."""
 import glob
@@ -12,7 +12,9 @@ import os
 import re
 import shutil
 
-SRC, DST = 'gpurun_out/r05_profiles', 'profiles'
+import sys
+R = sys.argv[1] if len(sys.argv) > 1 else 'r06'
+SRC, DST = 'gpurun_out/%s_profiles' % R, 'profiles'
 for name in ['bench_default.json', 'bench_c3.json', 'infer_c5.json', 'bench_force_allreduce.json', 'default_kernel_stats.csv', 'c3_kernel_stats.csv']:
     src = os.path.join(SRC, name)
     if not os.path.exists(src):
@@ -20,10 +22,10 @@ for name in ['bench_default.json', 'bench_c3.json', 'infer_c5.json', 'bench_forc
     if name.endswith('.json'):      # keep only the JSON line
         lines = [l for l in open(src) if l.startswith('{')]
         if lines:
-            with open(os.path.join(DST, 'r05_' + name), 'w') as f:
+            with open(os.path.join(DST, R + '_' + name), 'w') as f:
                 f.write(lines[-1])
     else:
-        shutil.copy(src, os.path.join(DST, 'r05_' + name))
+        shutil.copy(src, os.path.join(DST, R + '_' + name))
 
 
 def counters(tag, family):
@@ -50,10 +52,10 @@ def describe(k, c):
 
 NOTE = ('mean per dispatch, rocprofv3 --pmc passes (five separate runs per shape: three SQ groups, FETCH_SIZE, WRITE_SIZE) of tools/dcn_micro.py '
         '--iters 2 --ostd 1.25 at the L1 shape; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles, '
-        'FETCH/WRITE_SIZE KB (FETCH_SIZE x2 for bytes on gfx950; it counts fabric requests, Infinity-Cache hits included); tools/r05_profiles.sh')
+        'FETCH/WRITE_SIZE KB (FETCH_SIZE x2 for bytes on gfx950; it counts fabric requests, Infinity-Cache hits included); tools/profiles.sh')
 std = 1.25
 fwd_summary = {}
-for tag, B, C, out in (('fwd64', 40, 64, 'r05_dcn_fwd_pmc.json'), ('fwd128', 16, 128, 'r05_dcn_fwd_pmc_nf128.json')):
+for tag, B, C, out in (('fwd64', 40, 64, R + '_dcn_fwd_pmc.json'), ('fwd128', 16, 128, R + '_dcn_fwd_pmc_nf128.json')):
     fwd = counters(tag, 'dcn_fwd3')
     fwd_summary['dcn_fwd3_kernel nf%d B=%d' % (C, B)] = fwd
     describe('dcn_fwd3 nf%d' % C, fwd)
@@ -63,14 +65,14 @@ for tag, B, C, out in (('fwd64', 40, 64, 'r05_dcn_fwd_pmc.json'), ('fwd128', 16,
         hbm = (2 * fwd['FETCH_SIZE'] + fwd['WRITE_SIZE']) * 1024
         rec = {'kernel': 'dcn_fwd3_kernel', 'shape': {'B': B, 'C': C, 'Co': C, 'dg': 8, 'H': 180, 'W': 320, 'offset_std_px': std},
                'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python tools/dcn_micro.py --iters 2 --B %d --C %d --ostd %s --fwd-only '
-                          '(and a separate --pmc WRITE_SIZE pass); tools/r05_profiles.sh' % (B, C, std),
+                          '(and a separate --pmc WRITE_SIZE pass); tools/profiles.sh' % (B, C, std),
                'FETCH_SIZE_KB_reported': fwd['FETCH_SIZE'], 'fetch_correction': 'x2 (gfx950 FETCH_SIZE reports 1/2 of coalesced reads; calibrated in round 1, profiles/r01_notes.md)',
                'WRITE_SIZE_KB_reported': fwd['WRITE_SIZE'], 'hbm_bytes_per_launch': hbm, 'pixels_per_launch': px,
                'hbm_bytes_per_pixel': round(hbm / px, 1), 'algorithmic_bytes_per_pixel': alg}
         with open(os.path.join(DST, out), 'w') as f:
             json.dump(rec, f, indent=2)
         print(out, 'HBM bytes/px', rec['hbm_bytes_per_pixel'], 'vs algorithmic', alg)
-with open(os.path.join(DST, 'r05_dcn_sq_counters.json'), 'w') as f:
+with open(os.path.join(DST, R + '_dcn_sq_counters.json'), 'w') as f:
     json.dump({'note': NOTE + ' --fwd-only', 'counters': fwd_summary}, f, indent=1)
 
 bwd_summary = {}
@@ -83,7 +85,7 @@ for tag, B, C in (('bwd64', 40, 64), ('bwd128', 16, 128)):
                 c['hbm_bytes_per_pixel'] = round((2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 / px, 1)
             bwd_summary['%s_kernel nf%d B=%d' % (fam, C, B)] = c
             describe('%s nf%d' % (fam, C), c)
-with open(os.path.join(DST, 'r05_dcn_bwd_sq_counters.json'), 'w') as f:
+with open(os.path.join(DST, R + '_dcn_bwd_sq_counters.json'), 'w') as f:
     json.dump({'note': NOTE + ' (forward + backward of the pack; algorithmic bytes per pixel of the whole backward: 4 (2 C + 432 + Co) = %d at nf64, '
                               '%d at nf128; dcn_bwdin6 additionally writes and dcn_bwdw6 reads the 4 Co B/px transposed-gradient hand-off)' % (4 * (128 + 432 + 64), 4 * (256 + 432 + 128)),
                'counters': bwd_summary}, f, indent=1)
