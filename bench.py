@@ -916,7 +916,7 @@ def main():
     nl, kms, kbytes = timer.result()
     # HBM traffic of the DCN forward kernel: NOT measured here.  PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3
     # runs) are kept under profiles/; their bytes per output pixel are rescaled to the pixels an average timed launch covers.
-    traffic, traffic_source = None, None
+    traffic, traffic_source = None, None   # (roofline.traffic_basis: 'micro' = PMC passes of tools/dcn_micro.py in this run, 'profile record' = the file under profiles/)
     try:
         with open(os.path.join(ROOT, PMC_PROFILE[args.nf])) as f:
             pmc = json.load(f)
@@ -956,7 +956,8 @@ def main():
                        'offset_px_requested': args.offset_px,
                        'loss_last_step': round(float(loss.item()), 6)},
             'roofline': dict(dcn_roofline('dcn_fwd3_kernel (+ its weight pre-pack), fused DCN forward', args.nf, args.nf, gemm_mode, timer),
-                             traffic=traffic, traffic_source=traffic_source,
+                             traffic=traffic, traffic_source=traffic_source, traffic_basis=None if traffic is None else 'profile record',
+
                              dcn_bwd_ms_per_step=round(timer.backward_ms() / max(args.steps, 1), 3)),
         }
         if kms > 0:
@@ -1027,6 +1028,7 @@ def main():
             if bpp is not None:
                 line['roofline']['traffic'] = round(bpp * (kbytes / nl) / (4.0 * (args.nf + 216 + args.nf)))
                 line['roofline']['traffic_source'] = note
+                line['roofline']['traffic_basis'] = 'micro'   # counters of tools/dcn_micro.py (same kernel, L1 shape), rescaled -- not of the timed launches
             elif line['roofline'].get('traffic_source') is not None:
                 line['roofline']['traffic_source'] += '; live PMC pass unavailable: ' + note
         print(json.dumps(line), flush=True)
