@@ -57,7 +57,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 MFMA peak (no sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32
-PMC_PROFILE = {64: 'profiles/r05_dcn_fwd_pmc.json', 128: 'profiles/r05_dcn_fwd_pmc_nf128.json'}
+PMC_PROFILE = {64: 'profiles/r06_dcn_fwd_pmc.json', 128: 'profiles/r06_dcn_fwd_pmc_nf128.json'}
 
 
 def model_opt(args, world):
