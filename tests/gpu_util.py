@@ -17,7 +17,17 @@ def check(name, got, ref, tol):
     e = rel_err(got, ref)
     print('%-44s rel_err %.3e (tol %.1e)' % (name, e, tol))
     assert e <= tol, '%s: rel_err %.3e > %.1e' % (name, e, tol)
+    # max |a - b| / max |b| alone is loose wherever the tensor has small-magnitude regions (round-5 review): the relative L2 error of the whole
+    # tensor is held to the same tolerance class (the maximum error of a noise-like difference sits 3-5 sigma out, and so does the reference's
+    # maximum: the two ratios agree within a small factor unless the error is concentrated or structured)
+    if tol > 0 and ref.numel() > 1:
+        e2 = l2_err(got, ref)
+        print('%-44s l2_err  %.3e (bound %.1e)' % (name, e2, L2_FACTOR * tol))
+        assert e2 <= L2_FACTOR * tol, '%s: l2_err %.3e > %.1e' % (name, e2, L2_FACTOR * tol)
     return e
+
+
+L2_FACTOR = 3.0
 
 
 def l2_err(a, b):

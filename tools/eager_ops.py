@@ -21,6 +21,11 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for i in range(3):
         model.optimize_parameters(i + 4, log=False)
     torch.cuda.synchronize()
+import time
+evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+busy = sum(e.time_range.end - e.time_range.start for e in evs) / 3.0
+span = (max(e.time_range.end for e in evs) - min(e.time_range.start for e in evs)) / 3.0
+print('device kernels: %d per step, busy %.2f ms/step of a %.2f ms/step span (idle %.1f %%)' % (len(evs) / 3, busy / 1e3, span / 1e3, 100 * (1 - busy / span)))
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::') and e.device_time_total > 0]
 rows.sort(key=lambda e: -e.device_time_total)
 tot = 0.0
