@@ -740,6 +740,9 @@ int rvsr_launch_dcn_bwdin6(const DcnGeom& d, const float* weight, const TView& g
 // Three things this kernel taught (profiles/r05_notes.md): the untied first MFMA of an accumulator must keep its operands alive
 // (bf16x3.h: mfma_bf16_first); no rolled loop inside a divergent branch (the far path is unrolled: 32 loads in flight); two workgroups of four
 // waves per CU gave run-to-run different weight gradients for a reason that was not found -- one workgroup per CU does not.
+#ifndef RVSR_ABLW6
+#define RVSR_ABLW6 0   // scratch ablation builds (tools/build_variant.sh), results wrong by construction: 1 no operand LDS-DMA after the first tile, 2 no x
+#endif                 // loads, 4 no offset / mask loads, 8 no weight-gradient MFMAs, 16 no corner reads
 struct DcnBwdW6Params {
     DcnGeom d;
     const bf16x8* agt;  // gOut x act' as A operands, written by dcn_bwdin6 (bwd6_emit_agt): [b][row][x tile][mb32][ks][hi, lo][lane]
@@ -894,10 +897,10 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
             if (tl) TW6(10 + 4 * it);
             const float dy = act_lane ? o_dy[it] : 0.f, dx = act_lane ? o_dx[it] : 0.f;
             float m = o_m[it];
-            request_offsets(it, off_rs_n, msk_rs_n, pv_n);   // (the registers just read: the next tile's triple of this iteration)
-            if (it < 4) fetch_ag(bn, y0n, x0n, set ^ 1, 2 * it, 2 * it + 2);
+            if (!(RVSR_ABLW6 & 4)) request_offsets(it, off_rs_n, msk_rs_n, pv_n);   // (the registers just read: the next tile's triple of this iteration)
+            if (it < 4 && !(RVSR_ABLW6 & 1)) fetch_ag(bn, y0n, x0n, set ^ 1, 2 * it, 2 * it + 2);
 #pragma unroll
-            for (int k = it; k < NXI; k += 5) request_x_item(k, bn, y0n, x0n);   // (xv is free: committed to LDS above)
+            for (int k = it; k < NXI; k += 5) if (!(RVSR_ABLW6 & 2)) request_x_item(k, bn, y0n, x0n);   // (xv is free: committed to LDS above)
             if (d.mask_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));
             const float kyf = hi ? (float)(t1 / 3) : (float)(t0 / 3), kxf = hi ? (float)(t1 % 3) : (float)(t0 % 3);
             // sample position in IMAGE coordinates exactly as the reference forms it (kernel.cu:594-616)
@@ -919,7 +922,8 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float4* xq = xt + q * NPOS + pos0;
-                const float4 a00 = xq[0], a01 = xq[1], a10 = xq[TC], a11 = xq[TC + 1];
+                float4 a00 = xq[0], a01 = xq[1], a10 = xq[TC], a11 = xq[TC + 1];
+                if (RVSR_ABLW6 & 16) { a00 = make_float4(ly, lx, ml, ly); a01 = make_float4(lx, ly, ml, lx); a10 = a01; a11 = a00; }
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) {
                     const f32x2 c00 = ph ? f32x2{a00.z, a00.w} : f32x2{a00.x, a00.y};
@@ -974,6 +978,7 @@ __global__ __launch_bounds__(TH * 64, 2) void dcn_bwdw6_kernel(const DcnBwdW6Par
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) {
                         const bf16x8 ah = my_ag[(mb * 4 + ks * 2) * 64];
+                        if (RVSR_ABLW6 & 8) { gw_acc[mb][nb][ks] += (float)ah[0] * (float)bh[1] + (float)bl[2]; continue; }
                         gw_acc[mb][nb] = mfma_bf16(ah, bh, gw_acc[mb][nb]);
                         if (TERMS >= 2) gw_acc[mb][nb] = mfma_bf16(ah, bl, gw_acc[mb][nb]);
                         if (TERMS >= 3) gw_acc[mb][nb] = mfma_bf16(my_ag[(mb * 4 + ks * 2 + 1) * 64], bh, gw_acc[mb][nb]);
